@@ -1,0 +1,626 @@
+/*
+ * mf_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle / CPU baseline).
+ *
+ * Plain-C restatement of the reference's per-voxel hot path, written from the
+ * reference's algorithm description, loop order and branch structure so that it
+ * is bit-comparable with the reference's Python/Numba code.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
+ * The product (microstructure_fingerprinting_amd) never imports or links it.
+ *
+ * Pinned against the reference: tests/test_oracle_golden.py checks every function
+ * here against tests/golden/ (.npz files), which tests/golden/gen_golden.py produced by
+ * running the reference's own source in the build container.
+ *
+ * Citations: "mfu" = /root/reference/microstructure_fingerprinting/mf_utils.py,
+ *            "mf"  = /root/reference/microstructure_fingerprinting/mf.py.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
+ *        (no FMA contraction: the reference's CPython/Numba-without-fastmath
+ *        arithmetic rounds every product and sum separately).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_G_RANGE 1   /* mfu:1829-1836 ValueError: extrapolation in G not supported */
+#define ORC_ERR_ARG 2
+#define ORC_ERR_NNLS_ITER 3 /* scipy.optimize.nnls RuntimeError: max iterations */
+
+/* ------------------------------------------------------------------------- */
+/* 2-variable NNLS from precomputed scalars: mfu:404-459 (lsqnonneg_2var_opt),
+ * same case analysis as the inlined copy in mfu:341-379.                      */
+static void nnls2_scalars(double y_sq, double A11, double A12, double A22, double Y1, double Y2,
+                          double w[2], double* res_out) {
+  double A21 = A12;
+  double w1d = A22 * Y1 - A12 * Y2; /* mfu:425 */
+  double w2d = A11 * Y2 - A21 * Y1; /* mfu:426 */
+  double resnorm = y_sq;
+  w[0] = 0.0;
+  w[1] = 0.0;
+  if (w1d > 0.0 && w2d > 0.0) { /* mfu:432-439 */
+    double Det = A11 * A22 - A21 * A12;
+    w[0] = w1d / Det;
+    w[1] = w2d / Det;
+    resnorm = (resnorm + w[0] * w[0] * A11 + w[1] * w[1] * A22 +
+               2 * (w[0] * w[1] * A12 - w[0] * Y1 - w[1] * Y2));
+  } else if (w1d >= 0.0 && w2d <= 0.0) { /* mfu:440-444 */
+    if (Y1 >= 0.0) {
+      w[0] = Y1 / A11;
+      resnorm = resnorm - Y1 * w[0];
+    }
+  } else if (w1d <= 0.0 && w2d >= 0.0) { /* mfu:445-449 */
+    if (Y2 >= 0.0) {
+      w[1] = Y2 / A22;
+      resnorm = resnorm - Y2 * w[1];
+    }
+  } else if (w1d < 0.0 && w2d < 0.0) { /* mfu:450-458 */
+    if (Y1 > 0) {
+      w[0] = Y1 / A11;
+      resnorm -= Y1 * w[0];
+    } else if (Y2 > 0) {
+      w[1] = Y2 / A22;
+      resnorm -= Y2 * w[1];
+    }
+  }
+  *res_out = resnorm;
+}
+
+/* np.sum(y**2): NumPy pairwise summation (mfu:248, mfu:630).  For n < 8 a plain
+ * loop; otherwise 8 accumulators over blocks of <=128, recursive halving above. */
+static double np_pairwise_sumsq(const double* a, long n) {
+  if (n < 8) {
+    double res = 0.;
+    for (long i = 0; i < n; i++) res += a[i] * a[i];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    long i;
+    for (i = 0; i < 8; i++) r[i] = a[i] * a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; j++) r[j] += a[i + j] * a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i] * a[i];
+    return res;
+  } else {
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sumsq(a, n2) + np_pairwise_sumsq(a + n2, n - n2);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* solve_exhaustive_posweights_1: mfu:225-278 */
+static void solve1(const double* A, long lda, int M, long N, const double* y, double* w_out, long* sub,
+                   double* min_obj_out) {
+  double w_nneg = 0.0;
+  long ind = 0;
+  double y_sq = np_pairwise_sumsq(y, M); /* mfu:248 */
+  double min_obj = y_sq;
+  for (long i1 = 0; i1 < N; i1++) {
+    double adoty = 0.0, w = 0.0, resnorm = y_sq;
+    for (int i = 0; i < M; i++) adoty = adoty + A[i * lda + i1] * y[i]; /* mfu:258-259 */
+    if (adoty >= 0) {
+      double asq = 0.0;
+      for (int i = 0; i < M; i++) asq = asq + A[i * lda + i1] * A[i * lda + i1];
+      w = adoty / asq;
+      resnorm -= w * adoty; /* mfu:267 */
+    }
+    if (resnorm < min_obj) { /* mfu:270 strict */
+      ind = i1;
+      min_obj = resnorm;
+      w_nneg = w;
+    }
+  }
+  *w_out = w_nneg;
+  *sub = ind;
+  *min_obj_out = min_obj;
+}
+
+/* solve_exhaustive_posweights_2: mfu:288-392 */
+static int solve2(const double* A, long lda, int M, long N1, long N2, const double* y, double* w_out, long* sub,
+                  double* min_obj_out) {
+  double* A11 = (double*)calloc(N1, sizeof(double));
+  double* A22 = (double*)calloc(N2, sizeof(double));
+  double* A12 = (double*)calloc((size_t)N1 * N2, sizeof(double));
+  double* Ady = (double*)calloc(N1 + N2, sizeof(double));
+  if (!A11 || !A22 || !A12 || !Ady) return ORC_ERR_ARG;
+  for (long i1 = 0; i1 < N1; i1++) /* mfu:307-310 */
+    for (int k = 0; k < M; k++) A11[i1] += A[k * lda + i1] * A[k * lda + i1];
+  for (long i2 = 0; i2 < N2; i2++) /* mfu:311-314 */
+    for (int k = 0; k < M; k++) A22[i2] += A[k * lda + N1 + i2] * A[k * lda + N1 + i2];
+  for (long i1 = 0; i1 < N1; i1++) /* mfu:315-319 */
+    for (long i2 = 0; i2 < N2; i2++) {
+      double s = 0.0;
+      for (int k = 0; k < M; k++) s += A[k * lda + i1] * A[k * lda + N1 + i2];
+      A12[i1 * N2 + i2] = s;
+    }
+  double y_sq = 0.0;
+  for (int k = 0; k < M; k++) { /* mfu:320-325 */
+    y_sq += y[k] * y[k];
+    for (long i = 0; i < N1 + N2; i++) Ady[i] += y[k] * A[k * lda + i];
+  }
+  double min_obj = y_sq;
+  double wb[2] = {0, 0};
+  long s0 = 0, s1 = 0;
+  for (long i1 = 0; i1 < N1; i1++) /* mfu:329-386 */
+    for (long i2 = 0; i2 < N2; i2++) {
+      double w[2], res;
+      nnls2_scalars(y_sq, A11[i1], A12[i1 * N2 + i2], A22[i2], Ady[i1], Ady[N1 + i2], w, &res);
+      if (res < min_obj) {
+        s0 = i1;
+        s1 = i2;
+        min_obj = res;
+        wb[0] = w[0];
+        wb[1] = w[1];
+      }
+    }
+  w_out[0] = wb[0];
+  w_out[1] = wb[1];
+  sub[0] = s0;
+  sub[1] = s1;
+  *min_obj_out = min_obj;
+  free(A11); free(A22); free(A12); free(Ady);
+  return ORC_OK;
+}
+
+/* solve_exhaustive_posweights_3: mfu:470-607 */
+static int solve3(const double* A, long lda, int M, long N1, long N2, long N3, const double* y, double* w_out,
+                  long* sub, double* min_obj_out) {
+  const long s_ind[3] = {0, N1, N1 + N2};
+  const double eps = 2.2204e-16; /* mfu:480 */
+  const double tol = 100 * eps;
+  double* A11 = (double*)calloc(N1, sizeof(double));
+  double* A22 = (double*)calloc(N2, sizeof(double));
+  double* A33 = (double*)calloc(N3, sizeof(double));
+  double* A12 = (double*)calloc((size_t)N1 * N2, sizeof(double));
+  double* A13 = (double*)calloc((size_t)N1 * N3, sizeof(double));
+  double* A23 = (double*)calloc((size_t)N2 * N3, sizeof(double));
+  double* Ady = (double*)calloc(N1 + N2 + N3, sizeof(double));
+  if (!A11 || !A22 || !A33 || !A12 || !A13 || !A23 || !Ady) return ORC_ERR_ARG;
+#define COL(k, c) A[(k) * lda + (c)]
+  for (long i = 0; i < N1; i++)
+    for (int k = 0; k < M; k++) A11[i] += COL(k, s_ind[0] + i) * COL(k, s_ind[0] + i);
+  for (long i = 0; i < N2; i++)
+    for (int k = 0; k < M; k++) A22[i] += COL(k, s_ind[1] + i) * COL(k, s_ind[1] + i);
+  for (long i = 0; i < N3; i++)
+    for (int k = 0; k < M; k++) A33[i] += COL(k, s_ind[2] + i) * COL(k, s_ind[2] + i);
+  for (long i1 = 0; i1 < N1; i1++)
+    for (long i2 = 0; i2 < N2; i2++) {
+      double s = 0.0;
+      for (int k = 0; k < M; k++) s += COL(k, s_ind[0] + i1) * COL(k, s_ind[1] + i2);
+      A12[i1 * N2 + i2] = s;
+    }
+  for (long i3 = 0; i3 < N3; i3++)
+    for (long i1 = 0; i1 < N1; i1++) {
+      double s = 0.0;
+      for (int k = 0; k < M; k++) s += COL(k, s_ind[0] + i1) * COL(k, s_ind[2] + i3);
+      A13[i1 * N3 + i3] = s;
+    }
+  for (long i3 = 0; i3 < N3; i3++)
+    for (long i2 = 0; i2 < N2; i2++) {
+      double s = 0.0;
+      for (int k = 0; k < M; k++) s += COL(k, s_ind[1] + i2) * COL(k, s_ind[2] + i3);
+      A23[i2 * N3 + i3] = s;
+    }
+  double y_sq = 0.0;
+  for (int k = 0; k < M; k++) {
+    y_sq += y[k] * y[k];
+    for (long i = 0; i < N1 + N2 + N3; i++) Ady[i] += y[k] * COL(k, i);
+  }
+  double min_obj = y_sq;
+  double wb[3] = {0, 0, 0};
+  long sb[3] = {0, 0, 0};
+  for (long i3 = 0; i3 < N3; i3++) { /* mfu:540: i3 outermost */
+    double a33 = A33[i3], Y3 = Ady[s_ind[2] + i3];
+    for (long i1 = 0; i1 < N1; i1++) {
+      double a11 = A11[i1], a13 = A13[i1 * N3 + i3], Y1 = Ady[s_ind[0] + i1];
+      for (long i2 = 0; i2 < N2; i2++) {
+        double a12 = A12[i1 * N2 + i2], a22 = A22[i2], a23 = A23[i2 * N3 + i3], Y2 = Ady[s_ind[1] + i2];
+        double D1 = (Y1 * (a22 * a33 - a23 * a23) - Y2 * (a12 * a33 - a23 * a13) + Y3 * (a12 * a23 - a22 * a13));
+        double D2 = (-Y1 * (a12 * a33 - a13 * a23) + Y2 * (a11 * a33 - a13 * a13) - Y3 * (a11 * a23 - a12 * a13));
+        double D3 = (Y1 * (a12 * a23 - a13 * a22) - Y2 * (a11 * a23 - a12 * a13) + Y3 * (a11 * a22 - a12 * a12));
+        double w[3], res;
+        if (D1 >= -tol && D2 >= -tol && D3 >= -tol) { /* mfu:562-573 */
+          double D = (a11 * (a22 * a33 - a23 * a23) - a12 * (a12 * a33 - a23 * a13) + a13 * (a12 * a23 - a22 * a13));
+          w[0] = D1 / D;
+          w[1] = D2 / D;
+          w[2] = D3 / D;
+          res = 0.0;
+          for (int k = 0; k < M; k++) {
+            double t = (w[0] * COL(k, s_ind[0] + i1) + w[1] * COL(k, s_ind[1] + i2) + w[2] * COL(k, s_ind[2] + i3) - y[k]);
+            res += t * t;
+          }
+        } else { /* mfu:574-593 */
+          double w2[2], r2;
+          nnls2_scalars(y_sq, a11, a12, a22, Y1, Y2, w2, &r2);
+          w[0] = w2[0]; w[1] = w2[1]; w[2] = 0; res = r2;
+          nnls2_scalars(y_sq, a11, a13, a33, Y1, Y3, w2, &r2);
+          if (r2 < res) { w[0] = w2[0]; w[1] = 0; w[2] = w2[1]; res = r2; }
+          nnls2_scalars(y_sq, a22, a23, a33, Y2, Y3, w2, &r2);
+          if (r2 < res) { w[0] = 0; w[1] = w2[0]; w[2] = w2[1]; res = r2; }
+        }
+        if (res < min_obj) { /* mfu:596 */
+          sb[0] = i1; sb[1] = i2; sb[2] = i3;
+          min_obj = res;
+          wb[0] = w[0]; wb[1] = w[1]; wb[2] = w[2];
+        }
+      }
+    }
+  }
+#undef COL
+  for (int i = 0; i < 3; i++) { w_out[i] = wb[i]; sub[i] = sb[i]; }
+  *min_obj_out = min_obj;
+  free(A11); free(A22); free(A33); free(A12); free(A13); free(A23); free(Ady);
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Lawson-Hanson NNLS ("Solving Least Squares Problems", 1974/1995, ch. 23), the
+ * published algorithm behind scipy.optimize.nnls (SciPy 1.15.3, Cython port,
+ * called at mfu:640).  Third-party arithmetic: the reference has no test that
+ * reaches _4up, so this function is pinned only by the goldens generated with
+ * SciPy 1.15.3 in the build container (tests/golden/solver_cases.npz k4_*, k5_*).
+ * Small n (<= 16): unconstrained sub-problems solved by Householder QR on the
+ * passive columns.                                                            */
+#define NNLS_MAXN 16
+static void ls_passive(const double* As, int M, int n, const int* P, int np_, const double* b, double* s, double* work) {
+  /* solve min || As[:,P] z - b ||, z -> s[P], others 0.  work: M*(np_+1) doubles */
+  double* Q = work; /* column-major M x (np_+1): columns then rhs */
+  for (int c = 0; c < np_; c++)
+    for (int i = 0; i < M; i++) Q[c * M + i] = As[i * n + P[c]];
+  for (int i = 0; i < M; i++) Q[np_ * M + i] = b[i];
+  double diag[NNLS_MAXN];
+  for (int c = 0; c < np_; c++) {
+    double nrm = 0;
+    for (int i = c; i < M; i++) nrm += Q[c * M + i] * Q[c * M + i];
+    nrm = sqrt(nrm);
+    double alpha = (Q[c * M + c] > 0) ? -nrm : nrm;
+    double v0 = Q[c * M + c] - alpha;
+    double vnorm2 = v0 * v0;
+    for (int i = c + 1; i < M; i++) vnorm2 += Q[c * M + i] * Q[c * M + i];
+    diag[c] = alpha;
+    if (vnorm2 == 0) continue;
+    Q[c * M + c] = v0;
+    for (int c2 = c + 1; c2 <= np_; c2++) {
+      double dot = 0;
+      for (int i = c; i < M; i++) dot += Q[c * M + i] * Q[c2 * M + i];
+      double f = 2 * dot / vnorm2;
+      for (int i = c; i < M; i++) Q[c2 * M + i] -= f * Q[c * M + i];
+    }
+  }
+  double z[NNLS_MAXN];
+  for (int c = np_ - 1; c >= 0; c--) {
+    double t = Q[np_ * M + c];
+    for (int c2 = c + 1; c2 < np_; c2++) t -= Q[c2 * M + c] * z[c2];
+    z[c] = t / diag[c];
+  }
+  for (int i = 0; i < n; i++) s[i] = 0;
+  for (int c = 0; c < np_; c++) s[P[c]] = z[c];
+}
+
+static int nnls_lh(const double* As /* M x n row-major */, int M, int n, const double* b, double* x, double* rnorm,
+                   double* work /* M*(n+2) */) {
+  int inP[NNLS_MAXN] = {0};
+  double w[NNLS_MAXN], s[NNLS_MAXN];
+  double* resid = work + (size_t)M * (n + 1);
+  const int maxiter = 3 * n;
+  int iter = 0;
+  for (int i = 0; i < n; i++) x[i] = 0;
+  /* tolerance as in SciPy's implementation: 10 * max(m, n) * spacing(1) */
+  const double tol = 10.0 * (M > n ? M : n) * 2.220446049250313e-16;
+  for (int i = 0; i < M; i++) resid[i] = b[i];
+  for (;;) {
+    for (int j = 0; j < n; j++) {
+      double t = 0;
+      for (int i = 0; i < M; i++) t += As[i * n + j] * resid[i];
+      w[j] = t;
+    }
+    int jbest = -1;
+    double wbest = tol;
+    for (int j = 0; j < n; j++)
+      if (!inP[j] && w[j] > wbest) { wbest = w[j]; jbest = j; }
+    if (jbest < 0) break;
+    inP[jbest] = 1;
+    for (;;) {
+      int P[NNLS_MAXN], np_ = 0;
+      for (int j = 0; j < n; j++) if (inP[j]) P[np_++] = j;
+      ls_passive(As, M, n, P, np_, b, s, work);
+      int allpos = 1;
+      for (int c = 0; c < np_; c++) if (s[P[c]] <= 0) allpos = 0;
+      if (allpos) break;
+      if (++iter > maxiter) return ORC_ERR_NNLS_ITER;
+      double alpha = INFINITY;
+      for (int c = 0; c < np_; c++) {
+        int j = P[c];
+        if (s[j] <= 0) {
+          double a = x[j] / (x[j] - s[j]);
+          if (a < alpha) alpha = a;
+        }
+      }
+      for (int j = 0; j < n; j++) x[j] = x[j] + alpha * (s[j] - x[j]);
+      for (int j = 0; j < n; j++) if (inP[j] && x[j] <= tol) { inP[j] = 0; x[j] = 0; }
+      int any = 0;
+      for (int j = 0; j < n; j++) any |= inP[j];
+      if (!any) break;
+    }
+    for (int j = 0; j < n; j++) x[j] = s[j];
+    for (int i = 0; i < M; i++) {
+      double t = b[i];
+      for (int j = 0; j < n; j++) t -= As[i * n + j] * x[j];
+      resid[i] = t;
+    }
+  }
+  double r2 = 0;
+  for (int i = 0; i < M; i++) {
+    double t = b[i];
+    for (int j = 0; j < n; j++) t -= As[i * n + j] * x[j];
+    r2 += t * t;
+  }
+  *rnorm = sqrt(r2);
+  return ORC_OK;
+}
+
+/* solve_exhaustive_posweights_4up: mfu:612-657 (itertools.product order = last index fastest) */
+static int solve4up(const double* A, long lda, int M, const long* sizes, int Kp, const double* y, double* w_out,
+                    long* sub, double* min_obj_out) {
+  if (Kp > NNLS_MAXN) return ORC_ERR_ARG;
+  long st[NNLS_MAXN], idx[NNLS_MAXN];
+  long acc = 0;
+  for (int k = 0; k < Kp; k++) { st[k] = acc; acc += sizes[k]; idx[k] = 0; }
+  double* As = (double*)malloc(sizeof(double) * M * Kp);
+  double* work = (double*)malloc(sizeof(double) * M * (Kp + 2));
+  double y_sq = np_pairwise_sumsq(y, M); /* mfu:630 */
+  double min_obj = y_sq;
+  double wb[NNLS_MAXN];
+  long sb[NNLS_MAXN];
+  for (int k = 0; k < Kp; k++) { wb[k] = 0; sb[k] = 0; }
+  int rc = ORC_OK;
+  for (;;) {
+    for (int i = 0; i < M; i++)
+      for (int k = 0; k < Kp; k++) As[i * Kp + k] = A[i * lda + st[k] + idx[k]];
+    double x[NNLS_MAXN], rn;
+    rc = nnls_lh(As, M, Kp, y, x, &rn, work);
+    if (rc) break;
+    double obj = rn * rn; /* mfu:641 */
+    if (obj < min_obj) {
+      min_obj = obj;
+      for (int k = 0; k < Kp; k++) { wb[k] = x[k]; sb[k] = idx[k]; }
+    }
+    int k = Kp - 1;
+    while (k >= 0) {
+      if (++idx[k] < sizes[k]) break;
+      idx[k] = 0;
+      k--;
+    }
+    if (k < 0) break;
+  }
+  for (int k = 0; k < Kp; k++) { w_out[k] = wb[k]; sub[k] = sb[k]; }
+  *min_obj_out = min_obj;
+  free(As); free(work);
+  return rc;
+}
+
+/* solve_exhaustive_posweights: mfu:115-214 (dispatch; validation lives in the Python wrapper) */
+int orc_solve_exhaustive(const double* A, long lda, int M, const long* sizes, int Kp, const double* y, double* w,
+                         long* sub, long* tot, double* min_obj, double* y_rec) {
+  int rc = ORC_OK;
+  if (Kp == 1) solve1(A, lda, M, sizes[0], y, w, sub, min_obj);
+  else if (Kp == 2) rc = solve2(A, lda, M, sizes[0], sizes[1], y, w, sub, min_obj);
+  else if (Kp == 3) rc = solve3(A, lda, M, sizes[0], sizes[1], sizes[2], y, w, sub, min_obj);
+  else rc = solve4up(A, lda, M, sizes, Kp, y, w, sub, min_obj);
+  if (rc) return rc;
+  long acc = 0;
+  for (int k = 0; k < Kp; k++) { tot[k] = acc + sub[k]; acc += sizes[k]; }
+  /* y_recons = A[:, tot] @ w  (mfu:277, 391, 606, 655) */
+  for (int i = 0; i < M; i++) {
+    double t = 0.0;
+    for (int k = 0; k < Kp; k++) t += A[i * lda + tot[k]] * w[k];
+    y_rec[i] = (Kp == 1) ? w[0] * A[i * lda + tot[0]] : t;
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Rotation: interp_PGSE_from_multishell fast mode, mfu:1810-1955, on a flat
+ * table: S shells, sorted G_un[S], knots x[off[s]..off[s+1]) ascending,
+ * values Yk[(off[s]+j)*N + n].                                                */
+static inline long searchsorted_left(const double* x, long n, double v) {
+  long lo = 0, hi = n; /* first index with x[idx] >= v */
+  while (lo < hi) {
+    long mid = (lo + hi) / 2;
+    if (x[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* SciPy interp1d._call_linear for one new abscissa, all N columns */
+static void shell_eval(const double* x, const double* Yk, long P, int N, double u, double* out) {
+  long j = searchsorted_left(x, P, u);
+  if (j < 1) j = 1;
+  if (j > P - 1) j = P - 1;
+  const double* ylo = Yk + (j - 1) * N;
+  const double* yhi = Yk + j * N;
+  double dx = x[j] - x[j - 1], t = u - x[j - 1];
+  for (int n = 0; n < N; n++) {
+    double slope = (yhi[n] - ylo[n]) / dx;
+    out[n] = slope * t + ylo[n];
+  }
+}
+
+int orc_interp(int S, int N, const double* G_un, const int* off, const double* x, const double* Yk,
+               const double* sch, int M, const double* dir, double* out /* M x ldo */, long ldo, double* tmp /* 2N */) {
+  for (int m = 0; m < M; m++) {
+    const double* g = sch + 7 * m;
+    double u = fabs((g[0] * dir[0] + g[1] * dir[1]) + g[2] * dir[2]); /* mfu:1810 */
+    double G = g[3];
+    int sx = -1;
+    for (int s = 0; s < S; s++) if (G_un[s] == G) { sx = s; break; } /* mfu:1822 exact equality */
+    double* o = out + (long)m * ldo;
+    if (sx >= 0) {
+      shell_eval(x + off[sx], Yk + (long)off[sx] * N, off[sx + 1] - off[sx], N, u, o);
+    } else {
+      int ih = 0; /* np.argmax(Gms_un > Gnew), mfu:1829 */
+      for (int s = 0; s < S; s++) if (G_un[s] > G) { ih = s; break; }
+      if (ih == 0) return ORC_ERR_G_RANGE;
+      int il = ih - 1;
+      shell_eval(x + off[il], Yk + (long)off[il] * N, off[il + 1] - off[il], N, u, tmp);
+      shell_eval(x + off[ih], Yk + (long)off[ih] * N, off[ih + 1] - off[ih], N, u, tmp + N);
+      double dG = G_un[ih] - G_un[il], tG = G - G_un[il];
+      for (int n = 0; n < N; n++) { /* mfu:1950-1955 */
+        double slope = (tmp[N + n] - tmp[n]) / dG;
+        o[n] = slope * tG + tmp[n];
+      }
+    }
+  }
+  return ORC_OK;
+}
+
+/* rotate_atom's per-direction evaluation (mfu:1423-1426) on pre-built per-row shell tables:
+ * row m uses shell shell_of_row[m] (-1 = b0 row: copy sig, mfu:1298-1300); u = |g/|g| . n/|n||. */
+int orc_rotate_eval(int N, const int* off, const double* x, const double* Yk, const double* sch, int ldsch, int M,
+                    const int* shell_of_row, const double* sig, const double* newdir, double* out) {
+  double nn = sqrt((newdir[0] * newdir[0] + newdir[1] * newdir[1]) + newdir[2] * newdir[2]);
+  double d[3] = {newdir[0] / nn, newdir[1] / nn, newdir[2] / nn};
+  for (int m = 0; m < M; m++) {
+    const double* g = sch + (long)ldsch * m;
+    int s = shell_of_row[m];
+    if (s < 0) {
+      for (int n = 0; n < N; n++) out[(long)m * N + n] = sig[(long)m * N + n];
+      continue;
+    }
+    double gn = sqrt((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+    if (gn == 0) gn = INFINITY; /* mfu:1266 */
+    double u = fabs(((g[0] / gn) * d[0] + (g[1] / gn) * d[1]) + (g[2] / gn) * d[2]);
+    shell_eval(x + off[s], Yk + (long)off[s] * N, off[s + 1] - off[s], N, u, out + (long)m * N);
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* _fit_voxel: mf:340-461 */
+static double np_pairwise_sum(const double* a, long n) {
+  /* NumPy's pairwise summation (np.add.reduce on a contiguous double vector) */
+  if (n < 8) {
+    double res = 0.;
+    for (long i = 0; i < n; i++) res += a[i];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    long i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+  } else {
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+  }
+}
+static double np_mean(const double* a, int n) { return np_pairwise_sum(a, n) / n; }
+
+static int fit_voxel(int S, int N, const double* G_un, const int* off, const double* x, const double* Yk,
+                     const double* sch, int M, const double* y, int K, int csf_i, int ear_i, const double* peaks,
+                     int maxfasc, int csf_on, int ear_on, const double* sig_csf, const double* sig_ear, int E,
+                     double* D /* M x maxdic scratch */, long maxdic, double* tmp, double* y_rec, double* params) {
+  int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2; /* mf:381 */
+  for (int i = 0; i < num_params; i++) params[i] = 0.0;
+  if (K + csf_i + ear_i == 0) return ORC_OK; /* mf:387-388 */
+  long sizes[4];
+  int Kp = 0;
+  long dicsize = (long)K * N + (csf_i > 0) + (ear_i > 0) * E; /* mf:371-373 */
+  for (int k = 0; k < K; k++) { /* mf:391-397 */
+    int rc = orc_interp(S, N, G_un, off, x, Yk, sch, M, peaks + 3 * k, D + (long)k * N, maxdic, tmp);
+    if (rc) return rc;
+    sizes[Kp++] = N;
+  }
+  if (csf_i) { /* mf:401-403 */
+    for (int m = 0; m < M; m++) D[(long)m * maxdic + (long)K * N] = sig_csf[m];
+    sizes[Kp++] = 1;
+  }
+  if (ear_i) { /* mf:404-408 */
+    long st = (long)K * N + (csf_i > 0);
+    for (int m = 0; m < M; m++) for (int e = 0; e < E; e++) D[(long)m * maxdic + st + e] = sig_ear[(long)m * E + e];
+    sizes[Kp++] = E;
+  }
+  (void)dicsize;
+  double w[4], SoS;
+  long sub[4], tot[4];
+  int rc = orc_solve_exhaustive(D, maxdic, M, sizes, Kp, y, w, sub, tot, &SoS, y_rec);
+  if (rc) return rc;
+  double M0 = 0.0;
+  for (int k = 0; k < Kp; k++) M0 += w[k]; /* np.sum of <=4 values: plain loop */
+  double nu[4];
+  for (int k = 0; k < Kp; k++) nu[k] = (fabs(M0) > 0) ? w[k] / M0 : w[k]; /* mf:420-425 */
+  int i_csf = 2 * maxfasc + 1, i_ear = 2 * maxfasc + csf_on + 1;
+  int i_mse = 2 * maxfasc + csf_on + 2 * ear_on + 1, i_R2 = i_mse + 1;
+  params[0] = M0;
+  for (int k = 0; k < K; k++) { params[1 + k] = nu[k]; params[1 + maxfasc + k] = (double)sub[k]; }
+  if (csf_i) params[i_csf] = nu[K];
+  if (ear_i) { params[i_ear] = nu[K + (csf_i > 0)]; params[i_ear + 1] = (double)sub[K + (csf_i > 0)]; }
+  params[i_mse] = SoS / M;
+  /* R2 = corrcoef(y, y_rec)[0,1]**2 if M>1 and both std > 0 (mf:449-450) */
+  if (M > 1) {
+    double my = np_mean(y, M), mr = np_mean(y_rec, M);
+    double cyy = 0, crr = 0, cyr = 0;
+    for (int m = 0; m < M; m++) {
+      double a = y[m] - my, b = y_rec[m] - mr;
+      cyy += a * a; crr += b * b; cyr += a * b;
+    }
+    if (cyy > 0 && crr > 0) {
+      double f = (double)(M - 1);
+      double c00 = cyy / f, c11 = crr / f, c01 = cyr / f;
+      double r = c01 / sqrt(c00) / sqrt(c11);
+      if (r > 1) r = 1; if (r < -1) r = -1;
+      params[i_R2] = r * r;
+    }
+  }
+  return ORC_OK;
+}
+
+/* Voxel loop of MFModel.fit (mf:1017-1028 serial; mf:978-1009 process pool == nthreads>1 here) */
+int orc_fit_batch(int S, int N, const double* G_un, const int* off, const double* x, const double* Yk,
+                  const double* sch, int M, const double* Y /* V x M */, const int* Kv, const unsigned char* csfv,
+                  const unsigned char* earv, const double* peaks /* V x 3*maxfasc */, int maxfasc, int csf_on,
+                  int ear_on, const double* sig_csf, const double* sig_ear, int E, long V, double* params_out,
+                  int nthreads) {
+  int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  long maxdic = (long)maxfasc * N + csf_on + (long)ear_on * E;
+  if (maxdic < 1) maxdic = 1;
+  int err = 0;
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    double* D = (double*)calloc((size_t)M * maxdic, sizeof(double));
+    double* tmp = (double*)malloc(sizeof(double) * 2 * (N > 0 ? N : 1));
+    double* yrec = (double*)malloc(sizeof(double) * M);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long v = 0; v < V; v++) {
+      int rc = fit_voxel(S, N, G_un, off, x, Yk, sch, M, Y + v * M, Kv[v], csfv ? csfv[v] : 0, earv ? earv[v] : 0,
+                         peaks + v * 3 * maxfasc, maxfasc, csf_on, ear_on, sig_csf, sig_ear, E, D, maxdic, tmp, yrec,
+                         params_out + v * num_params);
+      if (rc) err = rc;
+    }
+    free(D); free(tmp); free(yrec);
+  }
+  return err;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

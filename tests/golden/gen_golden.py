@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference). Nothing here is
+imported by the product or shipped as code to the GPU box: the outputs are
+small ``.npz`` data files (inputs + the reference's outputs), committed.
+
+How the reference is executed: ``numba`` is not installed
+in this image, and ``mf_utils.py`` applies ``@nba.jit(...)`` at import time, so
+the package cannot be imported as-is (ordinary ImportError/TripWireError, not a
+permission denial).  We put a *pass-through* ``numba`` module (decorators return
+the undecorated function) in a temporary directory in front of ``sys.path``; the
+reference's own, unmodified Python source then runs as plain CPython with
+IEEE-754 double arithmetic in source order, which is what Numba's ``nopython``
+mode without ``fastmath`` computes as well.
+
+Usage:  python tests/golden/gen_golden.py [--only NAME]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+REF = "/root/reference"
+FIX = os.path.join(REF, "tests", "integration", "fixtures")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+NUMBA_STUB = textwrap.dedent('''
+    """pass-through stand-in: decorators are the identity."""
+    class _T:
+        def __getitem__(self, k): return self
+        def __call__(self, *a, **k): return self
+    class _Types:
+        def Tuple(self, *a, **k): return _T()
+        def UniTuple(self, *a, **k): return _T()
+    types = _Types()
+    float64 = int32 = int64 = int8 = float32 = _T()
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not isinstance(a[0], _T) and not k:
+            return a[0]
+        return lambda f: f
+    njit = jit
+''')
+
+
+def import_reference():
+    d = tempfile.mkdtemp(prefix="numba_passthrough_")
+    with open(os.path.join(d, "numba.py"), "w") as f:
+        f.write(NUMBA_STUB)
+    sys.path.insert(0, d)
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import microstructure_fingerprinting as mfpkg  # noqa
+    from microstructure_fingerprinting import mf_utils as mfu
+    from microstructure_fingerprinting import mf as mfmod
+    return mfu, mfmod
+
+
+# --------------------------------------------------------------------------
+# shared synthetic generators (kept in sync with the product's synth module by
+# storing the generated arrays themselves in the fixtures, not the recipe)
+# --------------------------------------------------------------------------
+GAM = 2 * np.pi * 42.577480e6
+
+
+def synth_scheme(rng, n_b0, shells_b, dirs_per_shell, Delta=43.1e-3, delta=10.6e-3, TE=92e-3):
+    rows = []
+    for _ in range(n_b0):
+        rows.append([0, 0, 0, 0.0, Delta, delta, TE])
+    for b, nd in zip(shells_b, dirs_per_shell):
+        G = np.sqrt(b * 1e6 / (Delta - delta / 3)) / (GAM * delta)
+        g = rng.standard_normal((nd, 3))
+        g /= np.linalg.norm(g, axis=1, keepdims=True)
+        for i in range(nd):
+            rows.append([g[i, 0], g[i, 1], g[i, 2], G, Delta, delta, TE])
+    return np.array(rows)
+
+
+def synth_dictionary(rng, sch, N):
+    """Smooth positive single-fascicle signals along z for N atoms on scheme sch."""
+    G, Dl, dl = sch[:, 3], sch[:, 4], sch[:, 5]
+    b = (GAM * G * dl) ** 2 * (Dl - dl / 3)
+    u = np.abs(sch[:, 2])
+    f = rng.uniform(0.3, 0.9, N)
+    dpar = rng.uniform(1.5e-9, 2.5e-9, N)
+    dperp = rng.uniform(0.1e-9, 0.8e-9, N)
+    Diso = rng.uniform(0.5e-9, 1.5e-9, N)
+    s0 = rng.uniform(0.5, 1.0, N)
+    u2 = (u ** 2)[:, None]
+    bb = b[:, None]
+    sig = s0 * (f * np.exp(-bb * dpar * u2) * np.exp(-bb * dperp * (1 - u2))
+                + (1 - f) * np.exp(-bb * Diso))
+    return sig
+
+
+def unit(rng, n):
+    v = rng.standard_normal((n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+# --------------------------------------------------------------------------
+def gen_solver(mfu):
+    """Random (A, y, dicsizes) problems for _1/_2/_3/_4up + the reference's
+    boundary tables (test_exhaustive_fingerprinting.py:38-89)."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    cases = [
+        ("k1_a", 30, [17]), ("k1_b", 12, [40]),
+        ("k2_a", 24, [13, 9]), ("k2_b", 40, [33, 35]), ("k2_c", 7, [5, 6]),
+        ("k3_a", 20, [9, 8, 1]), ("k3_b", 25, [7, 6, 5]), ("k3_c", 30, [12, 12, 3]),
+        ("k4_a", 20, [6, 5, 1, 3]), ("k4_b", 16, [4, 4, 2, 2]), ("k5_a", 14, [3, 3, 1, 2, 2]),
+    ]
+    names = []
+    for name, M, sizes in cases:
+        for variant in range(3):
+            nm = "%s_v%d" % (name, variant)
+            A = np.abs(rng.standard_normal((M, sum(sizes)))) if variant != 2 else rng.standard_normal((M, sum(sizes)))
+            st = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            gt = st + np.array([rng.integers(0, s) for s in sizes])
+            w = rng.uniform(0.1, 1.0, len(sizes))
+            if variant == 1:  # some weights zero -> exercises single-active branches
+                w[rng.integers(0, len(sizes))] = 0.0
+            y = A[:, gt] @ w + 0.05 * rng.standard_normal(M)
+            if variant == 2:
+                y = rng.standard_normal(M)  # arbitrary sign pattern
+            ds = np.array(sizes)
+            (wn, isub, itot, mo, yr) = mfu.solve_exhaustive_posweights(A, y, ds)
+            out[nm + "_A"] = A
+            out[nm + "_y"] = y
+            out[nm + "_sizes"] = ds
+            out[nm + "_w"] = np.asarray(wn, dtype=np.float64)
+            out[nm + "_sub"] = np.asarray(isub, dtype=np.int64)
+            out[nm + "_tot"] = np.asarray(itot, dtype=np.int64)
+            out[nm + "_obj"] = np.float64(mo)
+            out[nm + "_yrec"] = np.asarray(yr, dtype=np.float64)
+            names.append(nm)
+    out["names"] = np.array(names)
+
+    # reference boundary tables, re-run through the reference
+    s2, s3 = np.sqrt(2.0), np.sqrt(3.0)
+    A1 = np.array([[0.], [1.], [0.]])
+    Y1 = np.array([[1, 0, s2 / 2, 0, s2 / 2], [0, 0, -s2 / 2, 2, s2 / 2], [0, 1, 0, 0, 0]], dtype=float)
+    w1, o1 = [], []
+    for i in range(Y1.shape[1]):
+        r = mfu.solve_exhaustive_posweights(A1, Y1[:, i], np.array([1]))
+        w1.append(float(r[0][0])); o1.append(float(r[3]))
+    out["b1_A"], out["b1_Y"], out["b1_w"], out["b1_obj"] = A1, Y1, np.array(w1), np.array(o1)
+    A2 = np.array([[0.5, s3 * 0.5], [s3 * 0.5, 0.5]])
+    Y2 = np.array([[-s3 / 2, 0.5, -1, -s3 / 2, 0.5001, 0.5, s3 / 2, s2 / 2, -s2 / 2.0],
+                   [0.5, -s3 / 2, 0, 0.5001, -s3 / 2, s3 / 2, 0.5, s2 / 2, -s2 / 2.0]])
+    w2, o2 = [], []
+    for i in range(Y2.shape[1]):
+        r = mfu.solve_exhaustive_posweights(A2, Y2[:, i], np.array([1, 1]))
+        w2.append(np.array(r[0], dtype=float)); o2.append(float(r[3]))
+    out["b2_A"], out["b2_Y"], out["b2_w"], out["b2_obj"] = A2, Y2, np.array(w2).T, np.array(o2)
+    np.savez_compressed(os.path.join(OUT, "solver_cases.npz"), **out)
+    print("solver_cases.npz:", len(names), "cases")
+
+
+def gen_rotation(mfu):
+    """init_PGSE_multishell_interp tables + interp_PGSE_from_multishell outputs
+    (exact-G and G-bracketing) on a synthetic table and on the UKBB fixture
+    (atoms sub-sampled), + rotate_atom on the HCP fixture (atoms sub-sampled)."""
+    rng = np.random.default_rng(7)
+    out = {}
+    # --- synthetic table: 2 b0 + 3 shells
+    sch_ms = synth_scheme(rng, 2, [1000, 2000, 3000], [33, 34, 35])
+    # add a near-perpendicular cluster in shell 1 to exercise the left-edge merge
+    idx = np.where(sch_ms[:, 3] > 0)[0][:3]
+    for t, i in enumerate(idx):
+        v = np.array([np.cos(0.3 * t), np.sin(0.3 * t), 2e-4 * (t + 1)])
+        sch_ms[i, :3] = v / np.linalg.norm(v)
+    N = 23
+    dic = synth_dictionary(rng, sch_ms, N)
+    b0 = np.where(sch_ms[:, 3] == 0)[0]
+    dic[b0, :] = dic[b0[0], :]
+    ordir = np.array([0.0, 0.0, 1.0])
+    ms = mfu.init_PGSE_multishell_interp(dic, sch_ms, ordir)
+    out["syn_sch_ms"], out["syn_dic"], out["syn_ordir"] = sch_ms, dic, ordir
+    out["syn_Gms_un"] = ms["Gms_un"]
+    for s, f in enumerate(ms["interpolators"]):
+        out["syn_x_%d" % s] = np.asarray(f.x, dtype=float)
+        out["syn_y_%d" % s] = np.asarray(f.y, dtype=float)
+    # subject scheme A: subset/reorder of dense scheme rows (exact-G)
+    perm = rng.permutation(sch_ms.shape[0])[:60]
+    schA = sch_ms[perm].copy()
+    schA[:, :3] = np.where(schA[:, 3:4] > 0, unit(rng, 60), 0.0)
+    # subject scheme B: G values between shells (bracketing) + b0
+    schB = schA.copy()
+    Gs = np.unique(sch_ms[:, 3])
+    nz = schB[:, 3] > 0
+    schB[nz, 3] = rng.uniform(Gs[1], Gs[-1], nz.sum())
+    schB[nz, 3][:5] = Gs[2]
+    # a very small but nonzero G between the b0 shell and shell 1 is legal too
+    dirs = unit(rng, 6)
+    dirs[0] = ordir
+    dirs[1] = np.array([1.0, 0, 0])  # perpendicular: left extrapolation region
+    outA = np.stack([mfu.interp_PGSE_from_multishell(schA, d, msinterp=ms) for d in dirs])
+    outB = np.stack([mfu.interp_PGSE_from_multishell(schB, d, msinterp=ms) for d in dirs])
+    # slow (uninitialised) path must agree (reference's own test idea)
+    slowA = mfu.interp_PGSE_from_multishell(schA, dirs[2], dic, sch_ms, ordir)
+    assert np.max(np.abs(slowA - outA[2])) < 1e-12
+    out["syn_schA"], out["syn_schB"], out["syn_dirs"] = schA, schB, dirs
+    out["syn_outA"], out["syn_outB"] = outA, outB
+
+    # --- UKBB fixture (271 x 986), atoms subsampled to keep file small
+    uk = mfu.loadmat(os.path.join(FIX, "ukbb_90_dirs_dictionary_hcp_deltas.mat"))
+    sel = np.arange(0, uk["dictionary"].shape[1], 29)  # 34 atoms
+    dic_uk = np.ascontiguousarray(uk["dictionary"][:, sel])
+    ms_uk = mfu.init_PGSE_multishell_interp(dic_uk, uk["sch_mat"], uk["orientation"])
+    out["uk_sch_ms"], out["uk_dic"], out["uk_ordir"] = uk["sch_mat"], dic_uk, np.asarray(uk["orientation"], float)
+    out["uk_Gms_un"] = ms_uk["Gms_un"]
+    for s, f in enumerate(ms_uk["interpolators"]):
+        out["uk_x_%d" % s] = np.asarray(f.x, dtype=float)
+        out["uk_y_%d" % s] = np.asarray(f.y, dtype=float)
+    bvals = np.loadtxt(os.path.join(FIX, "1000521_bvals.txt"))
+    bvecs = np.loadtxt(os.path.join(FIX, "1000521_bvecs.txt"))
+    sch_subj = np.zeros((bvals.size, 7))
+    sch_subj[:, :3] = bvecs.T
+    sch_subj[:, 4:7] = uk["sch_mat"][0, 4:7]
+    sch_subj[:, 3] = np.sqrt(bvals * 1e6 / (sch_subj[:, 4] - sch_subj[:, 5] / 3)) / (GAM * sch_subj[:, 5])
+    sch_subj[:, 3] = np.minimum(sch_subj[:, 3], np.max(uk["sch_mat"][:, 3]))
+    dirs_uk = unit(rng, 4)
+    dirs_uk[0] = np.asarray(uk["orientation"], float)
+    out["uk_sch_subj"], out["uk_dirs"] = sch_subj, dirs_uk
+    out["uk_out_subj"] = np.stack([mfu.interp_PGSE_from_multishell(sch_subj, d, msinterp=ms_uk) for d in dirs_uk])
+    out["uk_out_dense"] = np.stack([mfu.interp_PGSE_from_multishell(uk["sch_mat"], d, msinterp=ms_uk) for d in dirs_uk])
+    # MC ground truth for the same atoms (reference test gate: max abs err < 1e-2)
+    gt = mfu.loadmat(os.path.join(FIX, "1000521_dictionary_hcp_deltas.mat"))
+    out["uk_mc_truth"] = np.ascontiguousarray(gt["dictionary"][:, sel])
+
+    # --- HCP fixture: rotate_atom (552 x 782 with 40 b0 prepended)
+    hcp = mfu.loadmat(os.path.join(FIX, "MC_dictionary_hcp.mat"))
+    sch = mfu.import_PGSE_scheme(os.path.join(FIX, "hcp_mgh_1003.scheme1"))
+    nb0 = 40
+    sch_b0 = np.vstack((np.zeros((nb0, sch.shape[1])), sch))
+    sch_b0[:nb0, 4:] = sch[0, 4:]
+    selh = np.arange(2, 782, 41)  # 20 atoms, includes 86? -> add explicitly
+    selh = np.unique(np.concatenate([selh, [86]]))
+    sig = np.ascontiguousarray(hcp["dic_fascicle_refdir"][:, selh])
+    S0 = np.ascontiguousarray(hcp["S0_fascicle"][:, selh])
+    dirs_h = unit(rng, 3)
+    refdir = np.array([0.0, 0.0, 1.0])
+    out["hcp_sch"], out["hcp_sig"], out["hcp_S0"] = sch_b0, sig, S0
+    out["hcp_DIFF"] = np.float64(hcp["WM_DIFF"])
+    out["hcp_dirs"], out["hcp_refdir"] = dirs_h, refdir
+    out["hcp_rot"] = np.stack([mfu.rotate_atom(sig, sch_b0, refdir, d, hcp["WM_DIFF"], S0) for d in dirs_h])
+    out["hcp_rot_1d"] = mfu.rotate_atom(sig[:, 3], sch_b0, refdir, dirs_h[1], hcp["WM_DIFF"], S0[:, 3])
+    np.savez_compressed(os.path.join(OUT, "rotation_cases.npz"), **out)
+    print("rotation_cases.npz written")
+
+
+def make_model_dict(rng, sch_ms, N, num_ear):
+    dic = synth_dictionary(rng, sch_ms, N)
+    b0 = np.where(sch_ms[:, 3] == 0)[0]
+    dic[b0, :] = dic[b0[0], :]
+    return {
+        "dictionary": dic, "sch_mat": sch_ms, "orientation": np.array([0.0, 0.0, 1.0]),
+        "num_atom": N, "num_ear": num_ear, "T2_csf": 2.0, "DIFF_csf": 3.0e-9,
+        "T2_ear": 0.08, "DIFF_ear": np.linspace(0.2e-9, 1.2e-9, num_ear),
+        "fasc_propnames": ["rad ", "fin"],
+        "rad": rng.uniform(0.2e-6, 2e-6, N), "fin": rng.uniform(0.2, 0.9, N),
+    }
+
+
+def gen_fit(mfu, mfmod):
+    """MFModel.fit end-to-end through the reference on a small mixed ROI:
+    K in {0,1,2}, CSF / EAR on subsets (exercises _1, _2, _3, _4up and the
+    params_vox packing, mf.py:340-461)."""
+    rng = np.random.default_rng(99)
+    sch_ms = synth_scheme(rng, 1, [1000, 2000, 3000], [20, 21, 22])
+    N, E = 14, 3
+    md = make_model_dict(rng, sch_ms, N, E)
+    model = mfmod.MFModel(dict(md))
+    ms = model.ms_interpolator
+    # subject scheme: exact-G rows + a few bracketed rows
+    sch = sch_ms.copy()
+    nzr = np.where(sch[:, 3] > 0)[0]
+    sch[nzr, :3] = unit(rng, nzr.size)
+    Gs = np.unique(sch_ms[:, 3])
+    sch[nzr[:7], 3] = rng.uniform(Gs[1], Gs[2], 7)
+    V = 24
+    numfasc = np.array([2] * 10 + [1] * 8 + [0] * 6)
+    csf = np.zeros(V, bool); ear = np.zeros(V, bool)
+    csf[[1, 2, 5, 11, 12, 18, 19, 22]] = True
+    ear[[2, 3, 6, 12, 13, 19, 20, 23]] = True  # voxel 21: K=0, no csf, no ear -> zeros
+    peaks = np.zeros((V, 6))
+    peaks[:, :3] = unit(rng, V); peaks[:, 3:] = unit(rng, V)
+    peaks[numfasc < 2, 3:] = 0
+    peaks[numfasc < 1, :3] = 0
+    b = (GAM * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / md["T2_csf"]) * np.exp(-b * md["DIFF_csf"])
+    sig_ear = np.stack([np.exp(-sch[:, 6] / md["T2_ear"]) * np.exp(-b * d) for d in md["DIFF_ear"]], axis=1)
+    Y = np.zeros((V, sch.shape[0]))
+    for v in range(V):
+        comps = []
+        for k in range(numfasc[v]):
+            Dk = mfu.interp_PGSE_from_multishell(sch, peaks[v, 3 * k:3 * k + 3], msinterp=ms)
+            comps.append(Dk[:, rng.integers(0, N)])
+        if csf[v]:
+            comps.append(sig_csf)
+        if ear[v]:
+            comps.append(sig_ear[:, rng.integers(0, E)])
+        if comps:
+            nu = rng.dirichlet(np.ones(len(comps)))
+            Y[v] = 500 * np.stack(comps, 1) @ nu
+        Y[v] += rng.normal(0, 500 / 30.0, sch.shape[0])
+    # voxel 9 (K=2): pure single-fascicle signal -> single-active tie-break path
+    D0 = mfu.interp_PGSE_from_multishell(sch, peaks[9, :3], msinterp=ms)
+    Y[9] = 400 * D0[:, 4]
+    mask = np.ones((4, 6))
+    data = Y.reshape(4, 6, -1)
+    fit = model.fit(data, mask, numfasc.reshape(4, 6), peaks=peaks.reshape(4, 6, 6), pgse_scheme=sch,
+                    csf_mask=csf.reshape(4, 6).astype(float), ear_mask=ear.reshape(4, 6).astype(float), verbose=0)
+    out = {"sch_ms": sch_ms, "sch": sch, "dictionary": md["dictionary"], "N": N, "E": E,
+           "T2_csf": md["T2_csf"], "DIFF_csf": md["DIFF_csf"], "T2_ear": md["T2_ear"], "DIFF_ear": md["DIFF_ear"],
+           "rad": md["rad"], "fin": md["fin"],
+           "numfasc": numfasc, "csf": csf, "ear": ear, "peaks": peaks, "Y": Y}
+    out["param_names"] = np.array(fit.param_names)
+    for p in fit.param_names:
+        out["map_" + p] = getattr(fit, p)
+    # raw params_in_mask rows via _fit_voxel semantics: re-run serial loop pieces
+    np.savez_compressed(os.path.join(OUT, "fit_cases.npz"), **out)
+    print("fit_cases.npz written; params:", fit.param_names)
+
+    # second case: no CSF/EAR anywhere, maxfasc = 1  (config-1-like plumbing)
+    V2 = 12
+    pk = unit(rng, V2)
+    Y2 = np.zeros((V2, sch.shape[0]))
+    for v in range(V2):
+        Dk = mfu.interp_PGSE_from_multishell(sch, pk[v], msinterp=ms)
+        Y2[v] = 300 * Dk[:, rng.integers(0, N)] + rng.normal(0, 5, sch.shape[0])
+    fit2 = model.fit(Y2, np.ones(V2), 1, peaks=pk, pgse_scheme=sch, verbose=0)
+    out2 = {"peaks": pk, "Y": Y2, "param_names": np.array(fit2.param_names)}
+    for p in fit2.param_names:
+        out2["map_" + p] = getattr(fit2, p)
+    np.savez_compressed(os.path.join(OUT, "fit_cases_k1.npz"), **out2)
+    print("fit_cases_k1.npz written; params:", fit2.param_names)
+
+
+def gen_c2_small(mfu, mfmod):
+    """A handful of config-2-shaped voxels (2 fascicles, M=200) at reduced N so the
+    CPython reference finishes in seconds; full params via MFModel.fit."""
+    rng = np.random.default_rng(1)
+    sch_ms = synth_scheme(rng, 2, [1000, 2000, 3000], [66, 66, 66])
+    N = 48
+    md = make_model_dict(rng, sch_ms, N, 2)
+    model = mfmod.MFModel(dict(md))
+    V = 6
+    peaks = np.concatenate([unit(rng, V), unit(rng, V)], axis=1)
+    ms = model.ms_interpolator
+    Y = np.zeros((V, sch_ms.shape[0]))
+    for v in range(V):
+        D1 = mfu.interp_PGSE_from_multishell(sch_ms, peaks[v, :3], msinterp=ms)
+        D2 = mfu.interp_PGSE_from_multishell(sch_ms, peaks[v, 3:], msinterp=ms)
+        nu = rng.dirichlet([1, 1])
+        Y[v] = 500 * (nu[0] * D1[:, rng.integers(0, N)] + nu[1] * D2[:, rng.integers(0, N)])
+        Y[v] += rng.normal(0, 500 / 30.0, sch_ms.shape[0])
+    fit = model.fit(Y, np.ones(V), 2, peaks=peaks, pgse_scheme=sch_ms, verbose=0)
+    out = {"sch_ms": sch_ms, "dictionary": md["dictionary"], "peaks": peaks, "Y": Y,
+           "param_names": np.array(fit.param_names), "rad": md["rad"], "fin": md["fin"]}
+    for p in fit.param_names:
+        out["map_" + p] = getattr(fit, p)
+    np.savez_compressed(os.path.join(OUT, "fit_c2_small.npz"), **out)
+    print("fit_c2_small.npz written")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    mfu, mfmod = import_reference()
+    todo = {"solver": lambda: gen_solver(mfu), "rotation": lambda: gen_rotation(mfu),
+            "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod)}
+    for k, fn in todo.items():
+        if a.only in (None, k):
+            fn()
