@@ -1,0 +1,112 @@
+/*
+ * mfx.h -- C ABI of the MI355X-native per-voxel fingerprint matcher.
+ *
+ * The reference (rensonnetg/microstructure_fingerprinting) is pure Python and has no
+ * FFI layer: the drop-in boundary is its Python call signatures.  Each entry point
+ * below is what a reference maintainer would bind (ctypes stub in INTEGRATION.md)
+ * behind one of those signatures; the reference interface it replaces is cited as
+ * file:line relative to /root/reference/microstructure_fingerprinting/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices row-major, float64; indices int32/int64.
+ *   - every function returns 0 on success or an MFX_ERR_* code; mfx_last_error() gives
+ *     the message (thread-local).  The Python wrapper maps codes to the exception
+ *     classes the reference raises (AssertionError / ValueError / RuntimeError).
+ *   - the caller owns every input/output buffer; the library copies host inputs to the
+ *     device and never keeps a host pointer after return.  Opaque handles (mfx_tables,
+ *     mfx_plan) are library-owned and freed by their *_destroy function.
+ *   - "_dev" variants take DEVICE pointers (HBM-resident inputs/outputs, e.g. torch
+ *     tensors' data_ptr) and a hipStream_t passed as void*; they enqueue work and do
+ *     not synchronise.
+ *   - there is no CPU fallback: every compute entry point fails with MFX_ERR_NO_DEVICE
+ *     when no gfx950 device is usable.
+ */
+#ifndef MFX_H
+#define MFX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_OK 0
+#define MFX_ERR_ARG 1          /* malformed argument (maps to AssertionError / ValueError) */
+#define MFX_ERR_G_RANGE 2      /* mf_utils.py:1829-1836 "Extrapolation not supported" -> ValueError */
+#define MFX_ERR_NO_DEVICE 3    /* no usable HIP device -> RuntimeError */
+#define MFX_ERR_HIP 4          /* HIP runtime failure -> RuntimeError */
+#define MFX_ERR_UNSUPPORTED 5  /* shape outside the kernels' limits -> NotImplementedError */
+#define MFX_ERR_DIR_NORM 6     /* mf_utils.py:1798-1802 non-unit fascicle direction -> ValueError */
+
+typedef struct mfx_tables mfx_tables; /* device-resident per-shell knot tables */
+typedef struct mfx_plan mfx_plan;     /* device-resident per-protocol row plan   */
+
+const char* mfx_last_error(void);
+int mfx_device_count(void);
+/* library/ABI version, bumped on any signature change */
+int mfx_abi_version(void);
+
+/* ---- tables: replaces the interpolator objects returned by
+ * init_PGSE_multishell_interp (mf_utils.py:1959-2085; dict keys at 2081-2085).
+ * knots_x   [P]      ascending within each shell (P = shell_off[S])
+ * knots_Y   [P x N]  row-major dictionary rows at the knots
+ * shell_off [S+1]
+ * G_un      [S]      sorted unique gradient strengths of the dense scheme
+ * The per-interval slopes (Y[j]-Y[j-1])/(x[j]-x[j-1]) of SciPy's interp1d._call_linear
+ * are precomputed once here (they are direction independent).                     */
+int mfx_tables_create(const double* knots_x, const int32_t* shell_off, const double* knots_Y,
+                      const double* G_un, int S, int N, int device, mfx_tables** out);
+void mfx_tables_destroy(mfx_tables* t);
+int mfx_tables_num_atoms(const mfx_tables* t);
+
+/* ---- plan: per-protocol row -> shell mapping.
+ * multishell: mf_utils.py:1810-1839 (exact float equality of G, else bracketing pair,
+ * MFX_ERR_G_RANGE outside the table range).  scheme [M x 7] = [gx gy gz G Delta delta TE].
+ * explicit: rotate_atom (mf_utils.py:1205-1437): the caller has already grouped rows
+ * into (G,Delta,delta) shells; gdirs [M x 3] are used as given, shell_of_row [M].   */
+int mfx_plan_create_multishell(const mfx_tables* t, const double* scheme, int M, mfx_plan** out);
+int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs, const int32_t* shell_of_row, int M,
+                             mfx_plan** out);
+void mfx_plan_destroy(mfx_plan* p);
+
+/* ---- batched rotation: B directions -> out [B x M x N].
+ * Replaces interp_PGSE_from_multishell(sch_mat, newdir, msinterp=...) (mf_utils.py:1693-1956)
+ * and the evaluation step of rotate_atom (mf_utils.py:1423-1426).
+ * normalise_dirs != 0 divides each direction by its norm first (rotate_atom, mf_utils.py:1269). */
+int mfx_rotate(const mfx_plan* p, const double* dirs, int64_t B, int normalise_dirs, double* out);
+int mfx_rotate_dev(const mfx_plan* p, const double* d_dirs, int64_t B, int normalise_dirs, double* d_out,
+                   void* stream);
+
+/* ---- the voxel loop: replaces MFModel.fit's loop over _fit_voxel
+ * (mf.py:976-1032 calling mf.py:340-461).
+ * Y       [V x M]           measured signals (ROI order)
+ * K       [V]               number of fascicles per voxel (0..maxfasc), maxfasc <= 2
+ * csf,ear [V] or NULL       per-voxel compartment flags
+ * peaks   [V x 3*maxfasc]   fascicle directions (unit norm +-1e-3, checked once per batch)
+ * sig_csf [M] / sig_ear [M x E]  (NULL when csf_on / ear_on is 0)
+ * params_out [V x num_params], num_params = 1 + 2*maxfasc + csf_on + 2*ear_on + 2,
+ * layout of mf.py:375-450.                                                          */
+int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf, const uint8_t* ear,
+                  const double* peaks, int maxfasc, int csf_on, int ear_on, const double* sig_csf,
+                  const double* sig_ear, int E, int64_t V, double* params_out);
+/* Device-resident variant: all pointers are device pointers.  Only the homogeneous class
+ * "every voxel has K == maxfasc, csf == csf_on, ear == ear_on" is accepted (that is what a
+ * benchmark or a pre-binned caller has); mixed batches go through mfx_fit_batch.        */
+int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int maxfasc, int csf_on,
+                      int ear_on, const double* d_sig_csf, const double* d_sig_ear, int E, int64_t V,
+                      double* d_params_out, void* stream);
+
+/* ---- explicit-dictionary solver: replaces solve_exhaustive_posweights(A, y, dicsizes)
+ * (mf_utils.py:115-214 and the kernels it dispatches to, 225-657).
+ * A [M x sum(dicsizes)] with leading dimension lda; outputs as the reference's 5-tuple. */
+int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const int64_t* dicsizes, int Kp, const double* y,
+                         double* w, int64_t* sub, int64_t* tot, double* min_obj, double* y_rec);
+
+/* Timing hook for bench.py: average device time (ms) of the dominant kernel of the last
+ * mfx_fit_batch*_ call on this thread, measured with hipEvents on the launch stream
+ * (valid after the stream has been synchronised); < 0 if unavailable.              */
+double mfx_last_kernel_ms(void);
+void mfx_set_profiling(int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,363 @@
+// fit_k2.hip -- fused per-voxel kernel for voxels with two fascicles (sub-dictionary sizes [N, N]).
+//
+// Replaces, for one voxel per workgroup, the reference chain
+//   _fit_voxel (mf.py:340-461) -> 2 x interp_PGSE_from_multishell (mf_utils.py:1693-1956)
+//   -> solve_exhaustive_posweights_2 (mf_utils.py:288-392) -> params_vox packing (mf.py:420-450).
+//
+// Structure (one 512-thread workgroup = 8 waves, 2 per SIMD, one voxel):
+//   phase 0  y -> LDS; per (direction,row) knot-interval descriptors (binary search) -> LDS
+//   phase 1  column statistics A11,Y1 (dictionary rotated to dir 0) and A22,Y2 (dir 1), one thread
+//            per atom, sequential over the M measurements exactly as mf_utils.py:307-325
+//   phase 2  the cross-Gram D1^T D2 on FP64 MFMA (v_mfma_f64_16x16x4_f64): each wave keeps the
+//            A operand (its 16 atoms of D1 over all M rows) in registers, generated straight from
+//            the L2-resident table; D2 is generated 32 atoms at a time into a double-buffered LDS
+//            tile shared by the 8 waves.  The 2x2 NNLS of mf_utils.py:341-379 is evaluated on the
+//            accumulator tile in registers, division-free (candidates are compared as fractions
+//            num/Det by cross-multiplication), keeping one best candidate per (lane,row).
+//   phase 3  candidates within 1e-9*||y||^2 of the best score are re-evaluated in the reference's
+//            exact arithmetic and loop order, the reference's strict-'<' first-hit rule picks the
+//            winner, and the voxel's parameters are written.
+// Rotated dictionaries are never materialised in HBM: per voxel the kernel reads y (M doubles),
+// two directions, and writes num_params doubles.
+#include "mfx_device.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MFX_WG 512
+#define MFX_MAXC 256
+
+struct FitK2Args {
+  TablesDev T;
+  PlanDev P;
+  const double* Y;      // [V x M]
+  const double* peaks;  // [V x peaks_ld]
+  int peaks_ld;
+  const int* vox_list;  // [nvox] or null (identity)
+  double* params;       // [V x num_params]
+  int num_params;
+  int maxfasc;
+  int csf_on, ear_on;
+};
+
+struct Cand {
+  double score;
+  int i, j;
+};
+
+// exact 2-variable NNLS on precomputed scalars, case analysis of mf_utils.py:341-379 / 425-458
+__device__ __forceinline__ void nnls2_exact(double y_sq, double A11, double A12, double A22, double Y1, double Y2,
+                                            double& w0, double& w1, double& res) {
+  const double d1 = A22 * Y1 - A12 * Y2;
+  const double d2 = A11 * Y2 - A12 * Y1;
+  w0 = 0.0;
+  w1 = 0.0;
+  res = y_sq;
+  if (d1 > 0.0 && d2 > 0.0) {
+    const double Det = A11 * A22 - A12 * A12;
+    w0 = d1 / Det;
+    w1 = d2 / Det;
+    res = (res + w0 * w0 * A11 + w1 * w1 * A22 + 2 * (w0 * w1 * A12 - w0 * Y1 - w1 * Y2));
+  } else if (d1 >= 0.0 && d2 <= 0.0) {
+    if (Y1 >= 0.0) { w0 = Y1 / A11; res = res - Y1 * w0; }
+  } else if (d1 <= 0.0 && d2 >= 0.0) {
+    if (Y2 >= 0.0) { w1 = Y2 / A22; res = res - Y2 * w1; }
+  } else if (d1 < 0.0 && d2 < 0.0) {
+    if (Y1 > 0) { w0 = Y1 / A11; res -= Y1 * w0; }
+    else if (Y2 > 0) { w1 = Y2 / A22; res -= Y2 * w1; }
+  }
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int KSTEPS, bool BRACKET>
+__global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
+  constexpr int MP = KSTEPS * 4;  // padded measurement count
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int M = a.P.M, N = a.T.N, ldn = a.T.ldn;
+  const int NP = ldn;  // atoms padded to a multiple of 16
+  const int ntiles = NP >> 4;
+  const double2* __restrict__ tab = a.T.tab;
+  const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
+
+  // ---- LDS carve-up
+  double* sB = smem;                            // [2 buf][2 tile][MP][16]
+  double* s_y = sB + 2 * 2 * MP * 16;           // [MP]
+  double* s_t0 = s_y + MP;                      // [2][MP]
+  double* s_t1 = s_t0 + 2 * MP;                 // [2][MP] (bracket only)
+  double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);  // [MP]
+  double* s_dG = s_tG + (BRACKET ? MP : 0);      // [MP]
+  double* s_A11 = s_dG + (BRACKET ? MP : 0);     // [NP]
+  double* s_Y1 = s_A11 + NP;
+  double* s_A22 = s_Y1 + NP;
+  double* s_Y2 = s_A22 + NP;
+  double* s_red = s_Y2 + NP;                    // [16] scratch
+  Cand* s_cand = (Cand*)(s_red + 16);           // [MFX_MAXC]
+  int* s_r0 = (int*)(s_cand + MFX_MAXC);        // [2][MP]
+  int* s_r1 = s_r0 + 2 * MP;                    // [2][MP] (bracket only)
+  int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);   // [4] counters
+
+  // ---- phase 0: y, descriptors
+  const double* __restrict__ yv = a.Y + (size_t)vox * M;
+  const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
+  for (int m = tid; m < MP; m += MFX_WG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int idx = tid; idx < 2 * MP; idx += MFX_WG) {
+    const int k = idx / MP, m = idx - k * MP;
+    RowDesc rd;
+    rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;  // padded rows -> the all-zero table row
+    if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
+    s_r0[idx] = rd.r0;
+    s_t0[idx] = rd.t0;
+    if (BRACKET) {
+      s_r1[idx] = rd.r1;
+      s_t1[idx] = rd.t1;
+      if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
+    }
+  }
+  if (tid == 0) { s_cnt[0] = 0; s_red[8] = 0.0; }
+  __syncthreads();
+
+  auto elem = [&](int k, int m, int n) -> double {
+    if (BRACKET) {
+      RowDesc rd;
+      rd.r0 = s_r0[k * MP + m]; rd.t0 = s_t0[k * MP + m];
+      rd.r1 = s_r1[k * MP + m]; rd.t1 = s_t1[k * MP + m];
+      return mfx_eval_br(tab, ldn, rd, s_tG[m], s_dG[m], n);
+    } else {
+      return mfx_eval(tab, ldn, s_r0[k * MP + m], s_t0[k * MP + m], n);
+    }
+  };
+
+  // ---- phase 1: column statistics, reference order (mf_utils.py:307-325), y_sq likewise
+  double y_sq = 0.0;
+  for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
+  for (int col = tid; col < 2 * NP; col += MFX_WG) {
+    const int k = col >= NP, n = col - k * NP;
+    double a2 = 0.0, ay = 0.0;
+    if (n < N) {
+      for (int m = 0; m < M; ++m) {
+        const double d = elem(k, m, n);
+        a2 += d * d;
+        ay += s_y[m] * d;
+      }
+    }
+    (k ? s_A22 : s_A11)[n] = a2;
+    (k ? s_Y2 : s_Y1)[n] = ay;
+  }
+  __syncthreads();
+
+  // generation of one 32-atom chunk of D2 into LDS buffer `buf`: thread -> (atom c, rows m0+16p)
+  auto gen_chunk = [&](int ch, int buf) {
+    const int c = tid & 31, m0 = tid >> 5;
+    const int n = ch * 32 + c;
+    double* dst = sB + (size_t)buf * (2 * MP * 16) + (c >> 4) * (MP * 16) + (c & 15);
+    if (n < NP) {
+#pragma unroll 4
+      for (int m = m0; m < MP; m += 16) dst[m * 16] = elem(1, m, n);
+    } else {
+      for (int m = m0; m < MP; m += 16) dst[m * 16] = 0.0;
+    }
+  };
+
+  const int nchunks = (ntiles + 1) >> 1;
+  const int nrounds = (ntiles + 7) >> 3;
+  const double eps_abs = 1e-9 * y_sq;
+  double gmax_run = 0.0;  // running best score (same value in every thread)
+
+  for (int round = 0; round < nrounds; ++round) {
+    const int rt = round * 8 + wave;
+    const bool rt_valid = rt < ntiles;  // wave-uniform
+    // A operand: this wave's 16 atoms of D1, all KSTEPS k-steps, in registers
+    double afr[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rt * 16 + lc) : 0.0;
+    // per-lane row statistics (rows lg + 4r of the tile)
+    double A11r[4], Y1r[4], s1r[4];
+    bool rowok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (rt_valid ? rt : 0) * 16 + lg + 4 * r;
+      A11r[r] = s_A11[i];
+      Y1r[r] = s_Y1[i];
+      rowok[r] = rt_valid && (i < N);
+      s1r[r] = (rowok[r] && Y1r[r] > 0.0) ? (Y1r[r] * Y1r[r]) / A11r[r] : 0.0;
+    }
+    double bp[4], bq[4];
+    int bj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bp[r] = 0.0; bq[r] = 1.0; bj[r] = -1; }
+
+    gen_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
+      if (rt_valid) {
+        const double* b0p = sB + (size_t)buf * (2 * MP * 16) + lg * 16 + lc;
+        const double* b1p = b0p + MP * 16;
+        d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          const double b0 = b0p[kk * 64];
+          const double b1 = b1p[kk * 64];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b1, acc1, 0, 0, 0);
+        }
+        // pair scan on the two accumulator tiles
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const d4 acc = t ? acc1 : acc0;
+          const int j = ch * 32 + t * 16 + lc;
+          const bool colok = j < N;
+          const double A22 = s_A22[j < NP ? j : 0], Y2 = s_Y2[j < NP ? j : 0];
+          const double s2 = (colok && Y2 > 0.0) ? (Y2 * Y2) / A22 : 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double A12 = acc[r];
+            const double d1 = fma(-A12, Y2, A22 * Y1r[r]);
+            const double d2 = fma(-A12, Y1r[r], A11r[r] * Y2);
+            const double Det = fma(-A12, A12, A11r[r] * A22);
+            const double num = fma(Y2, d2, Y1r[r] * d1);
+            const bool both = (d1 > 0.0) && (d2 > 0.0) && (Det > 0.0);
+            const double smax = fmax(s1r[r], s2);
+            double p = both ? num : smax;
+            const double q = both ? Det : 1.0;
+            p = (colok && rowok[r]) ? p : 0.0;
+            const bool better = p * bq[r] > bp[r] * q;
+            bp[r] = better ? p : bp[r];
+            bq[r] = better ? q : bq[r];
+            bj[r] = better ? j : bj[r];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- round end: candidates within eps of the running best
+    double sc[4];
+    double lmax = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = (bj[r] >= 0) ? bp[r] / bq[r] : -1.0;
+      lmax = fmax(lmax, sc[r]);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) s_red[wave] = lmax;
+    __syncthreads();
+    double rmax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) rmax = fmax(rmax, s_red[w]);
+    gmax_run = fmax(gmax_run, rmax);
+    const double thr = gmax_run - eps_abs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (bj[r] >= 0 && sc[r] >= thr && sc[r] > 0.0) {
+        const int slot = atomicAdd(&s_cnt[0], 1);
+        if (slot < MFX_MAXC) {
+          s_cand[slot].score = sc[r];
+          s_cand[slot].i = rt * 16 + lg + 4 * r;
+          s_cand[slot].j = bj[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 3: exact re-evaluation of the short list (reference arithmetic and order)
+  int ncand = s_cnt[0];
+  ncand = ncand > MFX_MAXC ? MFX_MAXC : ncand;
+  const double thr_final = gmax_run - eps_abs;
+  double my_res = INFINITY, my_w0 = 0.0, my_w1 = 0.0;
+  int my_i = 0, my_j = 0;
+  if (tid < ncand && s_cand[tid].score >= thr_final) {
+    my_i = s_cand[tid].i;
+    my_j = s_cand[tid].j;
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double d1 = elem(0, m, my_i), d2 = elem(1, m, my_j), ym = s_y[m];
+      a11 += d1 * d1;
+      a22 += d2 * d2;
+      a12 += d1 * d2;
+      y1 += ym * d1;
+      y2 += ym * d2;
+    }
+    nnls2_exact(y_sq, a11, a12, a22, y1, y2, my_w0, my_w1, my_res);
+  }
+  // winner: smallest residual; exact ties -> first pair in the reference's scan order (i1 outer, i2 inner)
+  __syncthreads();
+  double* s_res = (double*)sB;           // reuse the B buffers as scratch
+  double* s_w = s_res + MFX_MAXC;        // [MAXC][2]
+  int* s_ij = (int*)(s_w + 2 * MFX_MAXC);  // [MAXC][2]
+  if (tid < MFX_MAXC) {
+    s_res[tid] = my_res;
+    s_w[2 * tid] = my_w0;
+    s_w[2 * tid + 1] = my_w1;
+    s_ij[2 * tid] = my_i;
+    s_ij[2 * tid + 1] = my_j;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // mf_utils.py:327, 382: start from min_obj = y_sq at (0,0) with w = 0, strict '<'
+    double best = y_sq, w0 = 0.0, w1 = 0.0;
+    int bi = 0, bjx = 0;
+    long bidx = -1;
+    for (int c = 0; c < ncand; ++c) {
+      const double r = s_res[c];
+      const long idx = (long)s_ij[2 * c] * N + s_ij[2 * c + 1];
+      if (r < best || (r == best && bidx >= 0 && idx < bidx)) {
+        best = r; w0 = s_w[2 * c]; w1 = s_w[2 * c + 1]; bi = s_ij[2 * c]; bjx = s_ij[2 * c + 1]; bidx = idx;
+      }
+    }
+    // params packing, mf.py:420-450
+    const double M0 = w0 + w1;
+    const double nu0 = (fabs(M0) > 0) ? w0 / M0 : w0;
+    const double nu1 = (fabs(M0) > 0) ? w1 / M0 : w1;
+    // y_rec = A[:, tot] @ w and R^2 = corrcoef(y, y_rec)[0,1]^2 (mf.py:449-450)
+    double* s_yrec = s_res + 4 * MFX_MAXC;  // [MP] scratch inside the (now idle) B buffers
+    double sy = 0.0, sr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double yr = elem(0, m, bi) * w0 + elem(1, m, bjx) * w1;
+      s_yrec[m] = yr;
+      sy += s_y[m];
+      sr += yr;
+    }
+    sy = wave_sum(sy) / M;
+    sr = wave_sum(sr) / M;
+    double cyy = 0.0, crr = 0.0, cyr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double da = s_y[m] - sy, db = s_yrec[m] - sr;
+      cyy += da * da;
+      crr += db * db;
+      cyr += da * db;
+    }
+    cyy = wave_sum(cyy);
+    crr = wave_sum(crr);
+    cyr = wave_sum(cyr);
+    double r2 = 0.0;
+    if (M > 1 && cyy > 0.0 && crr > 0.0) {
+      const double f = (double)(M - 1);
+      double r = (cyr / f) / sqrt(cyy / f) / sqrt(crr / f);
+      r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+      r2 = r * r;
+    }
+    double* out = a.params + (size_t)vox * a.num_params;
+    if (lane == 0) {
+      out[0] = M0;
+      out[1] = nu0;
+      out[2] = nu1;
+      out[1 + a.maxfasc] = (double)bi;
+      out[2 + a.maxfasc] = (double)bjx;
+      out[a.num_params - 2] = best / M;
+      out[a.num_params - 1] = r2;
+    }
+  }
+}

@@ -1,0 +1,362 @@
+// mfx_api.hip -- host side of the C ABI declared in include/mfx.h.
+// Owns device tables/plans, bins voxels by compartment class, launches the HIP kernels.
+// There is deliberately no CPU compute path in this file: without a usable gfx950 device
+// every compute entry point returns MFX_ERR_NO_DEVICE.
+#include "../../include/mfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fit_k2.hip"
+#include "mfx_device.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static thread_local int g_ev_launches = 0;
+static thread_local bool g_ev_valid = false;
+static bool g_profiling = false;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess) return fail(MFX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* mfx_last_error(void) { return g_err.c_str(); }
+extern "C" int mfx_abi_version(void) { return 1; }
+extern "C" int mfx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" void mfx_set_profiling(int enabled) { g_profiling = enabled != 0; }
+extern "C" double mfx_last_kernel_ms(void) {
+  if (!g_ev_valid || !g_ev0 || !g_ev1 || g_ev_launches == 0) return -1.0;
+  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+  return (double)ms / g_ev_launches;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct mfx_tables {
+  int device = 0;
+  TablesDev d{};
+  std::vector<double> h_x, h_G;
+  std::vector<int> h_off;
+  void* dx = nullptr;
+  void* doff = nullptr;
+  void* dtab = nullptr;
+  void* dG = nullptr;
+};
+
+struct mfx_plan {
+  const mfx_tables* t = nullptr;
+  PlanDev d{};
+  void* dg = nullptr;
+  void* dslo = nullptr;
+  void* dshi = nullptr;
+  void* dtG = nullptr;
+  void* ddG = nullptr;
+};
+
+static int require_device(int device) {
+  int n = mfx_device_count();
+  if (n <= 0) return fail(MFX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail(MFX_ERR_ARG, "device %d out of range (have %d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  return MFX_OK;
+}
+
+extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off, const double* knots_Y,
+                                 const double* G_un, int S, int N, int device, mfx_tables** out) {
+  if (!knots_x || !shell_off || !knots_Y || !G_un || !out || S < 1 || N < 1)
+    return fail(MFX_ERR_ARG, "mfx_tables_create: null or empty argument");
+  if (int rc = require_device(device)) return rc;
+  const int P = shell_off[S];
+  for (int s = 0; s < S; ++s)
+    if (shell_off[s + 1] - shell_off[s] < 2) return fail(MFX_ERR_ARG, "shell %d has fewer than 2 knots", s);
+  const int ldn = (N + 15) / 16 * 16;
+  std::vector<double2> tab((size_t)(P + 1) * ldn, double2{0.0, 0.0});
+  for (int s = 0; s < S; ++s) {
+    for (int j = shell_off[s]; j < shell_off[s + 1]; ++j) {
+      const bool last = (j == shell_off[s + 1] - 1);
+      for (int n = 0; n < N; ++n) {
+        double sl = 0.0;
+        if (!last) {
+          // interp1d._call_linear: slope = (y_hi - y_lo) / (x_hi - x_lo)
+          sl = (knots_Y[(size_t)(j + 1) * N + n] - knots_Y[(size_t)j * N + n]) / (knots_x[j + 1] - knots_x[j]);
+        }
+        tab[(size_t)j * ldn + n] = double2{knots_Y[(size_t)j * N + n], sl};
+      }
+    }
+  }
+  mfx_tables* t = new mfx_tables();
+  t->device = device;
+  t->h_x.assign(knots_x, knots_x + P);
+  t->h_G.assign(G_un, G_un + S);
+  t->h_off.assign(shell_off, shell_off + S + 1);
+  HIPCHK(hipMalloc(&t->dx, sizeof(double) * P));
+  HIPCHK(hipMalloc(&t->doff, sizeof(int) * (S + 1)));
+  HIPCHK(hipMalloc(&t->dtab, sizeof(double2) * tab.size()));
+  HIPCHK(hipMalloc(&t->dG, sizeof(double) * S));
+  HIPCHK(hipMemcpy(t->dx, knots_x, sizeof(double) * P, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t->doff, shell_off, sizeof(int) * (S + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t->dtab, tab.data(), sizeof(double2) * tab.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t->dG, G_un, sizeof(double) * S, hipMemcpyHostToDevice));
+  t->d.S = S;
+  t->d.N = N;
+  t->d.ldn = ldn;
+  t->d.P = P;
+  t->d.x = (const double*)t->dx;
+  t->d.off = (const int*)t->doff;
+  t->d.tab = (const double2*)t->dtab;
+  t->d.G_un = (const double*)t->dG;
+  *out = t;
+  return MFX_OK;
+}
+
+extern "C" void mfx_tables_destroy(mfx_tables* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  (void)hipFree(t->dx);
+  (void)hipFree(t->doff);
+  (void)hipFree(t->dtab);
+  (void)hipFree(t->dG);
+  delete t;
+}
+extern "C" int mfx_tables_num_atoms(const mfx_tables* t) { return t ? t->d.N : 0; }
+
+static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g, const std::vector<int>& slo,
+                       const std::vector<int>& shi, const std::vector<double>& tG, const std::vector<double>& dG,
+                       mfx_plan** out) {
+  mfx_plan* p = new mfx_plan();
+  p->t = t;
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMalloc(&p->dg, sizeof(double) * 3 * M));
+  HIPCHK(hipMalloc(&p->dslo, sizeof(int) * M));
+  HIPCHK(hipMalloc(&p->dshi, sizeof(int) * M));
+  HIPCHK(hipMalloc(&p->dtG, sizeof(double) * M));
+  HIPCHK(hipMalloc(&p->ddG, sizeof(double) * M));
+  HIPCHK(hipMemcpy(p->dg, g.data(), sizeof(double) * 3 * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->dslo, slo.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->dshi, shi.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->dtG, tG.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->ddG, dG.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+  p->d.M = M;
+  p->d.g = (const double*)p->dg;
+  p->d.s_lo = (const int*)p->dslo;
+  p->d.s_hi = (const int*)p->dshi;
+  p->d.tG = (const double*)p->dtG;
+  p->d.dG = (const double*)p->ddG;
+  p->d.any_bracket = 0;
+  for (int m = 0; m < M; ++m) p->d.any_bracket |= (shi[m] >= 0);
+  *out = p;
+  return MFX_OK;
+}
+
+extern "C" int mfx_plan_create_multishell(const mfx_tables* t, const double* scheme, int M, mfx_plan** out) {
+  if (!t || !scheme || !out || M < 1) return fail(MFX_ERR_ARG, "mfx_plan_create_multishell: bad argument");
+  const int S = t->d.S;
+  std::vector<double> g(3 * (size_t)M), tG(M, 0.0), dG(M, 1.0);
+  std::vector<int> slo(M, 0), shi(M, -1);
+  for (int m = 0; m < M; ++m) {
+    const double* r = scheme + 7 * (size_t)m;
+    g[3 * m] = r[0]; g[3 * m + 1] = r[1]; g[3 * m + 2] = r[2];
+    const double G = r[3];
+    int sx = -1;
+    for (int s = 0; s < S; ++s)
+      if (t->h_G[s] == G) { sx = s; break; }  // exact float equality, mf_utils.py:1822
+    if (sx >= 0) { slo[m] = sx; continue; }
+    int ih = 0;  // np.argmax(Gms_un > Gnew), mf_utils.py:1829
+    for (int s = 0; s < S; ++s)
+      if (t->h_G[s] > G) { ih = s; break; }
+    if (ih == 0)
+      return fail(MFX_ERR_G_RANGE,
+                  "Gradient intensity %g is not in the [%g, %g] range spanned by the multi-shell sampling. "
+                  "Extrapolation not supported.", G, t->h_G[0], t->h_G[S - 1]);
+    slo[m] = ih - 1;
+    shi[m] = ih;
+    tG[m] = G - t->h_G[ih - 1];
+    dG[m] = t->h_G[ih] - t->h_G[ih - 1];
+  }
+  return plan_upload(t, M, g, slo, shi, tG, dG, out);
+}
+
+extern "C" int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs, const int32_t* shell_of_row, int M,
+                                        mfx_plan** out) {
+  if (!t || !gdirs || !shell_of_row || !out || M < 1) return fail(MFX_ERR_ARG, "mfx_plan_create_explicit: bad argument");
+  std::vector<double> g(gdirs, gdirs + 3 * (size_t)M), tG(M, 0.0), dG(M, 1.0);
+  std::vector<int> slo(M, 0), shi(M, -1);
+  for (int m = 0; m < M; ++m) {
+    if (shell_of_row[m] < 0 || shell_of_row[m] >= t->d.S) return fail(MFX_ERR_ARG, "row %d: shell %d out of range", m, shell_of_row[m]);
+    slo[m] = shell_of_row[m];
+  }
+  return plan_upload(t, M, g, slo, shi, tG, dG, out);
+}
+
+extern "C" void mfx_plan_destroy(mfx_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->t->device);
+  (void)hipFree(p->dg);
+  (void)hipFree(p->dslo);
+  (void)hipFree(p->dshi);
+  (void)hipFree(p->dtG);
+  (void)hipFree(p->ddG);
+  delete p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch
+static size_t k2_lds_bytes(int ksteps, bool bracket, int NP) {
+  const size_t MP = (size_t)ksteps * 4;
+  size_t dbl = 2 * 2 * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + 16;
+  size_t bytes = dbl * 8 + sizeof(Cand) * MFX_MAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
+  return bytes;
+}
+
+template <int KSTEPS, bool BRACKET>
+static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
+  const size_t lds = k2_lds_bytes(KSTEPS, BRACKET, a.T.ldn);
+  if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2 kernel needs %zu B of LDS (> 160 KiB): N=%d too large", lds, a.T.N);
+  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (g_profiling) {
+    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
+    HIPCHK(hipEventRecord(g_ev0, st));
+  }
+  hipLaunchKernelGGL(kern, dim3(nvox), dim3(MFX_WG), lds, st, a);
+  HIPCHK(hipGetLastError());
+  if (g_profiling) {
+    HIPCHK(hipEventRecord(g_ev1, st));
+    g_ev_launches = 1;
+    g_ev_valid = true;
+  }
+  return MFX_OK;
+}
+
+static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
+  const int M = a.P.M;
+  const bool br = a.P.any_bracket != 0;
+  if (M <= 64) return br ? launch_k2_t<16, true>(a, nvox, st) : launch_k2_t<16, false>(a, nvox, st);
+  if (M <= 200) return br ? launch_k2_t<50, true>(a, nvox, st) : launch_k2_t<50, false>(a, nvox, st);
+  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 200 in this build (got %d)", M);
+}
+
+extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int maxfasc, int csf_on,
+                                 int ear_on, const double* d_sig_csf, const double* d_sig_ear, int E, int64_t V,
+                                 double* d_params_out, void* stream) {
+  if (!p || !d_Y || !d_params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: bad argument");
+  if (V == 0) return MFX_OK;
+  if (int rc = require_device(p->t->device)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  if (maxfasc == 2 && !csf_on && !ear_on) {
+    FitK2Args a{};
+    a.T = p->t->d;
+    a.P = p->d;
+    a.Y = d_Y;
+    a.peaks = d_peaks;
+    a.peaks_ld = 3 * maxfasc;
+    a.vox_list = nullptr;
+    a.params = d_params_out;
+    a.num_params = num_params;
+    a.maxfasc = maxfasc;
+    if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
+    return launch_k2(a, (int)V, st);
+  }
+  (void)d_sig_csf; (void)d_sig_ear; (void)E;
+  return fail(MFX_ERR_UNSUPPORTED, "class (K=%d, csf=%d, ear=%d) not implemented yet", maxfasc, csf_on, ear_on);
+}
+
+extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,
+                             const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
+                             const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {
+  if (!p || !Y || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
+  if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (int rc = require_device(p->t->device)) return rc;
+  const int M = p->d.M;
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  std::memset(params_out, 0, sizeof(double) * (size_t)V * num_params);
+  if (V == 0) return MFX_OK;
+  // direction check once per batch (the reference checks per voxel, mf_utils.py:1798-1802)
+  for (int64_t v = 0; v < V; ++v)
+    for (int k = 0; k < K[v]; ++k) {
+      const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * k;
+      const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      if (!(std::fabs(1 - nrm) <= 1e-3))
+        return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
+    }
+  // bin voxels by class
+  std::vector<int> cls_k2;
+  for (int64_t v = 0; v < V; ++v) {
+    const int c = csf ? (csf[v] != 0) : 0, e = ear ? (ear[v] != 0) : 0;
+    if (K[v] == 2 && !c && !e) cls_k2.push_back((int)v);
+    else if (K[v] + c + e == 0) continue;  // mf.py:387-388: all-zero row
+    else return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented yet", K[v], c, e);
+  }
+  (void)sig_csf; (void)sig_ear; (void)E;
+  double *dY = nullptr, *dpk = nullptr, *dpar = nullptr;
+  int* dlist = nullptr;
+  HIPCHK(hipMalloc(&dY, sizeof(double) * (size_t)V * M));
+  HIPCHK(hipMalloc(&dpk, sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1)));
+  HIPCHK(hipMalloc(&dpar, sizeof(double) * (size_t)V * num_params));
+  HIPCHK(hipMemcpy(dY, Y, sizeof(double) * (size_t)V * M, hipMemcpyHostToDevice));
+  if (maxfasc > 0) HIPCHK(hipMemcpy(dpk, peaks, sizeof(double) * (size_t)V * 3 * maxfasc, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dpar, 0, sizeof(double) * (size_t)V * num_params));
+  int rc = MFX_OK;
+  if (!cls_k2.empty()) {
+    HIPCHK(hipMalloc(&dlist, sizeof(int) * cls_k2.size()));
+    HIPCHK(hipMemcpy(dlist, cls_k2.data(), sizeof(int) * cls_k2.size(), hipMemcpyHostToDevice));
+    FitK2Args a{};
+    a.T = p->t->d;
+    a.P = p->d;
+    a.Y = dY;
+    a.peaks = dpk;
+    a.peaks_ld = 3 * maxfasc;
+    a.vox_list = dlist;
+    a.params = dpar;
+    a.num_params = num_params;
+    a.maxfasc = maxfasc;
+    rc = launch_k2(a, (int)cls_k2.size(), nullptr);
+  }
+  if (rc == MFX_OK) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(e));
+  }
+  if (rc == MFX_OK) {
+    hipError_t e = hipMemcpy(params_out, dpar, sizeof(double) * (size_t)V * num_params, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(dY); (void)hipFree(dpk); (void)hipFree(dpar); (void)hipFree(dlist);
+  return rc;
+}
+
+// entry points not built yet in this translation unit return MFX_ERR_UNSUPPORTED (never a CPU result)
+extern "C" int mfx_rotate(const mfx_plan*, const double*, int64_t, int, double*) {
+  return fail(MFX_ERR_UNSUPPORTED, "mfx_rotate not built yet");
+}
+extern "C" int mfx_rotate_dev(const mfx_plan*, const double*, int64_t, int, double*, void*) {
+  return fail(MFX_ERR_UNSUPPORTED, "mfx_rotate_dev not built yet");
+}
+extern "C" int mfx_solve_exhaustive(const double*, int64_t, int, const int64_t*, int, const double*, double*, int64_t*,
+                                    int64_t*, double*, double*) {
+  return fail(MFX_ERR_UNSUPPORTED, "mfx_solve_exhaustive not built yet");
+}

@@ -1,0 +1,94 @@
+// mfx_device.h -- device-side data layout shared by the HIP kernels and the host C-ABI.
+//
+// HBM layout
+//   tables  tab[(P+1) x ldn] of double2 {Ylo, slope}: row r = knot row (global index over all
+//           shells), column n = atom.  slope[r][n] = (Y[r+1][n]-Y[r][n]) / (x[r+1]-x[r]) is the
+//           per-interval slope of SciPy's interp1d._call_linear (reference call sites
+//           mf_utils.py:1423, 2038, 2074), precomputed once because it is direction independent.
+//           Row P is all zeros (used for padded measurement rows).  ldn = N rounded up to 16 so
+//           that 16-atom MFMA tiles never need a bounds check (padded atoms are zero).
+//   plan    per protocol row m: unit gradient g[m][3], shell index s_lo[m], and for rows whose
+//           G lies strictly between two table shells (mf_utils.py:1827-1839) s_hi[m] >= 0 with
+//           tG = G - G_lo, dG = G_hi - G_lo.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct TablesDev {
+  int S, N, ldn, P;
+  const double* x;     // [P]
+  const int* off;      // [S+1]
+  const double2* tab;  // [(P+1) x ldn]
+  const double* G_un;  // [S]
+};
+
+struct PlanDev {
+  int M;
+  const double* g;   // [M x 3]
+  const int* s_lo;   // [M]
+  const int* s_hi;   // [M]  (-1: exact shell)
+  const double* tG;  // [M]
+  const double* dG;  // [M]
+  int any_bracket;
+};
+
+// per-(direction,row) evaluation descriptor: which knot interval, and the offset inside it
+struct RowDesc {
+  int r0, r1;     // knot rows (r1 = -1 when the row maps to exactly one shell)
+  double t0, t1;  // u - x[r]
+};
+
+// np.searchsorted(x, v, side='left'): first index with x[idx] >= v
+__device__ __forceinline__ int mfx_searchsorted_left(const double* __restrict__ x, int n, double v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (x[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// interp1d._call_linear index logic: j = clip(searchsorted(x,u), 1, P_s-1); interval (j-1, j)
+__device__ __forceinline__ void mfx_shell_locate(const TablesDev& T, int s, double u, int& r, double& t) {
+  const int o = T.off[s];
+  const int Ps = T.off[s + 1] - o;
+  int j = mfx_searchsorted_left(T.x + o, Ps, u);
+  j = j < 1 ? 1 : j;
+  j = j > Ps - 1 ? Ps - 1 : j;
+  r = o + j - 1;
+  t = u - T.x[r];
+}
+
+// |g . d| with the reference's operation order ((g0 d0 + g1 d1) + g2 d2), mf_utils.py:1810
+__device__ __forceinline__ double mfx_absdot(const double* __restrict__ g, double d0, double d1, double d2) {
+  return fabs((g[0] * d0 + g[1] * d1) + g[2] * d2);
+}
+
+__device__ __forceinline__ RowDesc mfx_row_desc(const TablesDev& T, const PlanDev& P, int m, double d0, double d1,
+                                                double d2) {
+  RowDesc rd;
+  const double u = mfx_absdot(P.g + 3 * m, d0, d1, d2);
+  mfx_shell_locate(T, P.s_lo[m], u, rd.r0, rd.t0);
+  rd.r1 = -1;
+  rd.t1 = 0.0;
+  const int sh = P.s_hi[m];
+  if (sh >= 0) mfx_shell_locate(T, sh, u, rd.r1, rd.t1);
+  return rd;
+}
+
+// one rotated dictionary entry, exact-shell row:  slope * (u - x_lo) + y_lo  (separate mul and
+// add, as NumPy evaluates it; the translation unit is compiled with -ffp-contract=off)
+__device__ __forceinline__ double mfx_eval(const double2* __restrict__ tab, int ldn, int r, double t, int n) {
+  const double2 e = tab[(size_t)r * ldn + n];
+  return e.y * t + e.x;
+}
+
+// bracketed row: linear interpolation in G between the two shell values, mf_utils.py:1950-1955
+__device__ __forceinline__ double mfx_eval_br(const double2* __restrict__ tab, int ldn, const RowDesc& rd, double tG,
+                                              double dG, int n) {
+  const double v0 = mfx_eval(tab, ldn, rd.r0, rd.t0, n);
+  if (rd.r1 < 0) return v0;
+  const double v1 = mfx_eval(tab, ldn, rd.r1, rd.t1, n);
+  const double sl = (v1 - v0) / dG;
+  return sl * tG + v0;
+}

@@ -1,0 +1,101 @@
+"""Thin object layer over the C ABI: device tables, protocol plans, batched fit."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceTables:
+    """Per-shell knot tables resident in HBM (mfx_tables)."""
+
+    def __init__(self, xs, Ys, G_un, device=0):
+        self.xs = [np.ascontiguousarray(x, dtype=np.float64) for x in xs]
+        self.Ys = [np.ascontiguousarray(y, dtype=np.float64) for y in Ys]
+        self.G_un = np.ascontiguousarray(G_un, dtype=np.float64)
+        self.N = int(self.Ys[0].shape[1])
+        self.S = len(self.xs)
+        self.device = device
+        self._h = None
+        self.off = np.concatenate([[0], np.cumsum([x.size for x in self.xs])]).astype(np.int32)
+
+    def handle(self):
+        if self._h is None:
+            x = np.ascontiguousarray(np.concatenate(self.xs))
+            Y = np.ascontiguousarray(np.concatenate(self.Ys, axis=0))
+            h = C.c_void_p()
+            L.check(L.lib().mfx_tables_create(L.dptr(x), L.iptr(self.off), L.dptr(Y), L.dptr(self.G_un), self.S,
+                                             self.N, self.device, C.byref(h)))
+            self._h = h
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            L.lib().mfx_tables_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Per-protocol row->shell mapping resident in HBM (mfx_plan)."""
+
+    def __init__(self, tables, scheme=None, gdirs=None, shell_of_row=None):
+        self.tables = tables
+        h = C.c_void_p()
+        if scheme is not None:
+            sch = L.f64c(scheme)
+            if sch.ndim != 2 or sch.shape[1] != 7:
+                raise ValueError("pgse_scheme should have 7 columns")
+            self.M = sch.shape[0]
+            L.check(L.lib().mfx_plan_create_multishell(tables.handle(), L.dptr(sch), self.M, C.byref(h)))
+        else:
+            g = L.f64c(gdirs)
+            s = np.ascontiguousarray(shell_of_row, dtype=np.int32)
+            self.M = g.shape[0]
+            L.check(L.lib().mfx_plan_create_explicit(tables.handle(), L.dptr(g), L.iptr(s), self.M, C.byref(h)))
+        self._h = h
+
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            L.lib().mfx_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def num_params(maxfasc, csf_on, ear_on):
+    return 1 + 2 * maxfasc + int(csf_on) + 2 * int(ear_on) + 2   # mf.py:381
+
+
+def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0):
+    """Host-buffer voxel loop (mfx_fit_batch): returns params_in_mask [V x num_params] (mf.py:1018-1028)."""
+    Y = L.f64c(Y)
+    V, M = Y.shape
+    if M != plan.M:
+        raise ValueError("data has %d measurements, protocol has %d" % (M, plan.M))
+    K = np.ascontiguousarray(K, dtype=np.int32)
+    csf_a = np.ascontiguousarray(csf, dtype=np.uint8) if csf is not None else np.zeros(V, np.uint8)
+    ear_a = np.ascontiguousarray(ear, dtype=np.uint8) if ear is not None else np.zeros(V, np.uint8)
+    pk = L.f64c(peaks).reshape(V, -1) if maxfasc > 0 else np.zeros((V, 3))
+    if maxfasc > 0 and pk.shape[1] != 3 * maxfasc:
+        raise ValueError("peaks should have %d columns" % (3 * maxfasc))
+    out = np.zeros((V, num_params(maxfasc, csf_on, ear_on)))
+    sc = L.f64c(sig_csf) if sig_csf is not None else None
+    se = L.f64c(sig_ear) if sig_ear is not None else None
+    L.check(L.lib().mfx_fit_batch(plan.handle(), L.dptr(Y), L.iptr(K), L.bptr(csf_a), L.bptr(ear_a), L.dptr(pk),
+                                  int(maxfasc), int(csf_on), int(ear_on),
+                                  L.dptr(sc) if sc is not None else None, L.dptr(se) if se is not None else None,
+                                  int(E), V, L.dptr(out)))
+    return out
