@@ -74,6 +74,12 @@ void mfx_plan_destroy(mfx_plan* p);
 int mfx_rotate(const mfx_plan* p, const double* dirs, int64_t B, int normalise_dirs, double* out);
 int mfx_rotate_dev(const mfx_plan* p, const double* d_dirs, int64_t B, int normalise_dirs, double* d_out,
                    void* stream);
+/* one atom per direction: out [B x M] = rotated atom cols[b] (the reference's rotate_atom /
+ * interp_PGSE_from_multishell called with a single 1-D signal, mf_utils.py:1242-1243, 1764-1765) */
+int mfx_rotate_cols(const mfx_plan* p, const double* dirs, const int32_t* cols, int64_t B, int normalise_dirs,
+                    double* out);
+int mfx_rotate_cols_dev(const mfx_plan* p, const double* d_dirs, const int32_t* d_cols, int64_t B,
+                        int normalise_dirs, double* d_out, void* stream);
 
 /* ---- the voxel loop: replaces MFModel.fit's loop over _fit_voxel
  * (mf.py:976-1032 calling mf.py:340-461).

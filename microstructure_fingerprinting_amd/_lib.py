@@ -20,7 +20,7 @@ EXPORTS = [
     "mfx_last_error", "mfx_device_count", "mfx_abi_version",
     "mfx_tables_create", "mfx_tables_destroy", "mfx_tables_num_atoms",
     "mfx_plan_create_multishell", "mfx_plan_create_explicit", "mfx_plan_destroy",
-    "mfx_rotate", "mfx_rotate_dev", "mfx_fit_batch", "mfx_fit_batch_dev",
+    "mfx_rotate", "mfx_rotate_dev", "mfx_rotate_cols", "mfx_rotate_cols_dev", "mfx_fit_batch", "mfx_fit_batch_dev",
     "mfx_solve_exhaustive", "mfx_last_kernel_ms", "mfx_set_profiling",
 ]
 
@@ -56,6 +56,8 @@ def lib():
     L.mfx_plan_destroy.restype = None
     L.mfx_rotate.argtypes = [vp, dp, C.c_int64, C.c_int, dp]
     L.mfx_rotate_dev.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp]
+    L.mfx_rotate_cols.argtypes = [vp, dp, ip, C.c_int64, C.c_int, dp]
+    L.mfx_rotate_cols_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_int, vp, vp]
     L.mfx_fit_batch.argtypes = [vp, dp, ip, bp, bp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int64, dp]
     L.mfx_fit_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp]
     L.mfx_solve_exhaustive.argtypes = [dp, C.c_int64, C.c_int, lp, C.c_int, dp, dp, lp, lp, dp, dp]

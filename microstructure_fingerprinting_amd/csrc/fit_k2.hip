@@ -25,6 +25,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFX_WG 512
 #define MFX_MAXC 256
+#define MFX_DET_REL 1e-8   // pairs with 1 - cos^2 below this are ranked as single atoms
+#define MFX_A12_REL 4e-14  // bound on the relative rounding difference of an MFMA-summed Gram entry
 
 struct FitK2Args {
   TablesDev T;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   const int nchunks = (ntiles + 1) >> 1;
   const int nrounds = (ntiles + 7) >> 3;
   const double eps_abs = 1e-9 * y_sq;
-  double gmax_run = 0.0;  // running best score (same value in every thread)
+  double glb_run = 0.0;  // running best lower bound on the score (same value in every thread)
 
   for (int round = 0; round < nrounds; ++round) {
     const int rt = round * 8 + wave;
@@ -226,9 +228,12 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
             const double A12 = acc[r];
             const double d1 = fma(-A12, Y2, A22 * Y1r[r]);
             const double d2 = fma(-A12, Y1r[r], A11r[r] * Y2);
-            const double Det = fma(-A12, A12, A11r[r] * A22);
+            const double pd = A11r[r] * A22;
+            const double Det = fma(-A12, A12, pd);
             const double num = fma(Y2, d2, Y1r[r] * d1);
-            const bool both = (d1 > 0.0) && (d2 > 0.0) && (Det > 0.0);
+            // (numerically) collinear atom pairs carry no two-atom information: rank them by their
+            // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
+            const bool both = (d1 > 0.0) && (d2 > 0.0) && (Det > MFX_DET_REL * pd);
             const double smax = fmax(s1r[r], s2);
             double p = both ? num : smax;
             const double q = both ? Det : 1.0;
@@ -242,28 +247,35 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       }
       __syncthreads();
     }
-    // ---- round end: candidates within eps of the running best
-    double sc[4];
-    double lmax = 0.0;
+    // ---- round end: short-list by interval: a candidate stays if its upper bound reaches the best
+    // lower bound seen so far.  Bounds: eps_abs (formula/rounding differences between the fraction
+    // form and the reference's expression) plus the conditioning-dependent error of num/Det.
+    double sc[4], er[4];
+    double llb = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sc[r] = (bj[r] >= 0) ? bp[r] / bq[r] : -1.0;
-      lmax = fmax(lmax, sc[r]);
+      sc[r] = -1.0;
+      er[r] = 0.0;
+      if (bj[r] >= 0) {
+        sc[r] = bp[r] / bq[r];
+        const double pd = A11r[r] * s_A22[bj[r]];
+        er[r] = (bq[r] == 1.0) ? 0.0 : sc[r] * (MFX_A12_REL * pd / bq[r]);
+        llb = fmax(llb, sc[r] - er[r]);
+      }
     }
-    lmax = wave_max(lmax);
-    if (lane == 0) s_red[wave] = lmax;
+    llb = wave_max(llb);
+    if (lane == 0) s_red[wave] = llb;
     __syncthreads();
-    double rmax = s_red[0];
+    double rlb = s_red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) rmax = fmax(rmax, s_red[w]);
-    gmax_run = fmax(gmax_run, rmax);
-    const double thr = gmax_run - eps_abs;
+    for (int w = 1; w < 8; ++w) rlb = fmax(rlb, s_red[w]);
+    glb_run = fmax(glb_run, rlb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (bj[r] >= 0 && sc[r] >= thr && sc[r] > 0.0) {
+      if (bj[r] >= 0 && sc[r] > 0.0 && sc[r] + er[r] + eps_abs >= glb_run) {
         const int slot = atomicAdd(&s_cnt[0], 1);
         if (slot < MFX_MAXC) {
-          s_cand[slot].score = sc[r];
+          s_cand[slot].score = sc[r] + er[r] + eps_abs;   // upper bound
           s_cand[slot].i = rt * 16 + lg + 4 * r;
           s_cand[slot].j = bj[r];
         }
@@ -273,56 +285,98 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   }
 
   // ---- phase 3: exact re-evaluation of the short list (reference arithmetic and order)
-  int ncand = s_cnt[0];
-  ncand = ncand > MFX_MAXC ? MFX_MAXC : ncand;
-  const double thr_final = gmax_run - eps_abs;
-  double my_res = INFINITY, my_w0 = 0.0, my_w1 = 0.0;
-  int my_i = 0, my_j = 0;
-  if (tid < ncand && s_cand[tid].score >= thr_final) {
-    my_i = s_cand[tid].i;
-    my_j = s_cand[tid].j;
+  // exact (res, w) of one pair: sequential sums over the measurements as mf_utils.py:307-325, then
+  // the case analysis of mf_utils.py:341-379
+  auto exact_pair = [&](int i, int j, double& w0, double& w1, double& res) {
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0;
     for (int m = 0; m < M; ++m) {
-      const double d1 = elem(0, m, my_i), d2 = elem(1, m, my_j), ym = s_y[m];
+      const double d1 = elem(0, m, i), d2 = elem(1, m, j), ym = s_y[m];
       a11 += d1 * d1;
       a22 += d2 * d2;
       a12 += d1 * d2;
       y1 += ym * d1;
       y2 += ym * d2;
     }
-    nnls2_exact(y_sq, a11, a12, a22, y1, y2, my_w0, my_w1, my_res);
-  }
-  // winner: smallest residual; exact ties -> first pair in the reference's scan order (i1 outer, i2 inner)
-  __syncthreads();
-  double* s_res = (double*)sB;           // reuse the B buffers as scratch
-  double* s_w = s_res + MFX_MAXC;        // [MAXC][2]
-  int* s_ij = (int*)(s_w + 2 * MFX_MAXC);  // [MAXC][2]
-  if (tid < MFX_MAXC) {
-    s_res[tid] = my_res;
-    s_w[2 * tid] = my_w0;
-    s_w[2 * tid + 1] = my_w1;
-    s_ij[2 * tid] = my_i;
-    s_ij[2 * tid + 1] = my_j;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    // mf_utils.py:327, 382: start from min_obj = y_sq at (0,0) with w = 0, strict '<'
-    double best = y_sq, w0 = 0.0, w1 = 0.0;
-    int bi = 0, bjx = 0;
-    long bidx = -1;
-    for (int c = 0; c < ncand; ++c) {
-      const double r = s_res[c];
-      const long idx = (long)s_ij[2 * c] * N + s_ij[2 * c + 1];
-      if (r < best || (r == best && bidx >= 0 && idx < bidx)) {
-        best = r; w0 = s_w[2 * c]; w1 = s_w[2 * c + 1]; bi = s_ij[2 * c]; bjx = s_ij[2 * c + 1]; bidx = idx;
-      }
+    nnls2_exact(y_sq, a11, a12, a22, y1, y2, w0, w1, res);
+  };
+  // lexicographic (res, idx) minimum over the workgroup; idx = i*N + j is the reference's scan order
+  double* s_rres = (double*)sB;               // [8] per-wave partials (B buffers are idle now)
+  long* s_ridx = (long*)(s_rres + 8);         // [8]
+  double* s_rw = (double*)(s_ridx + 8);       // [8][2]
+  double* s_win = s_rw + 16;                  // winner: res, w0, w1, (long) idx
+  auto block_argmin = [&](double res, long idx, double w0, double w1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double r2 = __shfl_xor(res, o), u0 = __shfl_xor(w0, o), u1 = __shfl_xor(w1, o);
+      const long i2 = __shfl_xor(idx, o);
+      const bool take = (r2 < res) || (r2 == res && i2 < idx);
+      res = take ? r2 : res; idx = take ? i2 : idx; w0 = take ? u0 : w0; w1 = take ? u1 : w1;
     }
+    __syncthreads();
+    if (lane == 0) { s_rres[wave] = res; s_ridx[wave] = idx; s_rw[2 * wave] = w0; s_rw[2 * wave + 1] = w1; }
+    __syncthreads();
+    if (tid == 0) {
+      // fold into the current winner (strict '<' on res, ties -> earlier pair in scan order)
+      double br = s_win[0], b0 = s_win[1], b1 = s_win[2];
+      long bi = ((long*)s_win)[3];
+      for (int w = 0; w < 8; ++w) {
+        const double r = s_rres[w];
+        const long ix = s_ridx[w];
+        if (r < br || (r == br && bi >= 0 && ix >= 0 && ix < bi)) { br = r; bi = ix; b0 = s_rw[2 * w]; b1 = s_rw[2 * w + 1]; }
+      }
+      s_win[0] = br; s_win[1] = b0; s_win[2] = b1; ((long*)s_win)[3] = bi;
+    }
+    __syncthreads();
+  };
+  int ncand = s_cnt[0];
+  ncand = ncand > MFX_MAXC ? MFX_MAXC : ncand;
+  __syncthreads();   // everyone has read s_cnt / is done with the B buffers
+  if (tid == 0) {    // mf_utils.py:327, 382: start from min_obj = y_sq at pair (0,0) with w = 0, strict '<'
+    s_win[0] = y_sq; s_win[1] = 0.0; s_win[2] = 0.0; ((long*)s_win)[3] = -1;
+  }
+  {
+    double res = INFINITY, w0 = 0.0, w1 = 0.0;
+    long idx = -1;
+    if (tid < ncand && s_cand[tid].score >= glb_run) {
+      exact_pair(s_cand[tid].i, s_cand[tid].j, w0, w1, res);
+      idx = (long)s_cand[tid].i * N + s_cand[tid].j;
+    }
+    block_argmin(res, idx, w0, w1);
+  }
+  // Near-zero second weight: every pair sharing the active atom fits equally well up to rounding
+  // (e.g. a single-fascicle signal fitted with two fascicles).  The reference then returns the first
+  // pair of that row/column attaining the minimum of its own rounded residual: evaluate the whole
+  // family exactly.  Wave-uniform branch on the broadcast winner.
+  for (int pass = 0; pass < 2; ++pass) {
+    const double bw0 = s_win[1], bw1 = s_win[2];
+    const long bidx = ((long*)s_win)[3];
+    if (bidx < 0) break;
+    const int bi = (int)(bidx / N), bj2 = (int)(bidx - (long)bi * N);
+    const bool row_family = (pass == 0) && (bw1 <= 1e-7 * bw0);
+    const bool col_family = (pass == 1) && (bw0 <= 1e-7 * bw1);
+    if (!row_family && !col_family) continue;
+    double res = INFINITY, w0 = 0.0, w1 = 0.0;
+    long idx = -1;
+    for (int n = tid; n < N; n += MFX_WG) {
+      double r, u0, u1;
+      const int i = row_family ? bi : n, j = row_family ? n : bj2;
+      exact_pair(i, j, u0, u1, r);
+      const long ix = (long)i * N + j;
+      if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+    }
+    block_argmin(res, idx, w0, w1);
+  }
+  if (wave == 0) {
+    const double best = s_win[0], w0 = s_win[1], w1 = s_win[2];
+    const long bidx = ((long*)s_win)[3];
+    const int bi = bidx < 0 ? 0 : (int)(bidx / N);
+    const int bjx = bidx < 0 ? 0 : (int)(bidx - (long)bi * N);
     // params packing, mf.py:420-450
     const double M0 = w0 + w1;
     const double nu0 = (fabs(M0) > 0) ? w0 / M0 : w0;
     const double nu1 = (fabs(M0) > 0) ? w1 / M0 : w1;
     // y_rec = A[:, tot] @ w and R^2 = corrcoef(y, y_rec)[0,1]^2 (mf.py:449-450)
-    double* s_yrec = s_res + 4 * MFX_MAXC;  // [MP] scratch inside the (now idle) B buffers
+    double* s_yrec = s_win + 8;  // [MP] scratch inside the (now idle) B buffers
     double sy = 0.0, sr = 0.0;
     for (int m = lane; m < M; m += 64) {
       const double yr = elem(0, m, bi) * w0 + elem(1, m, bjx) * w1;

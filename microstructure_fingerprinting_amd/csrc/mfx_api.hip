@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "fit_k2.hip"
+#include "rotate.hip"
 #include "mfx_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -349,13 +350,80 @@ extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* 
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// rotation
+extern "C" int mfx_rotate_dev(const mfx_plan* p, const double* d_dirs, int64_t B, int normalise_dirs, double* d_out,
+                              void* stream) {
+  if (!p || !d_dirs || !d_out || B < 0) return fail(MFX_ERR_ARG, "mfx_rotate_dev: bad argument");
+  if (B == 0) return MFX_OK;
+  if (int rc = require_device(p->t->device)) return rc;
+  const int M = p->d.M;
+  for (int64_t b0 = 0; b0 < B; b0 += 32768) {  // gridDim.y limit
+    const int nb = (int)std::min<int64_t>(32768, B - b0);
+    dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, nb);
+    hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, (hipStream_t)stream, p->t->d, p->d,
+                       d_dirs + 3 * b0, normalise_dirs, d_out + (size_t)b0 * M * p->t->d.N);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_rotate(const mfx_plan* p, const double* dirs, int64_t B, int normalise_dirs, double* out) {
+  if (!p || !dirs || !out || B < 0) return fail(MFX_ERR_ARG, "mfx_rotate: bad argument");
+  if (B == 0) return MFX_OK;
+  if (int rc = require_device(p->t->device)) return rc;
+  const size_t n_out = (size_t)B * p->d.M * p->t->d.N;
+  double *dd = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&dd, sizeof(double) * 3 * B));
+  HIPCHK(hipMalloc(&dout, sizeof(double) * n_out));
+  HIPCHK(hipMemcpy(dd, dirs, sizeof(double) * 3 * B, hipMemcpyHostToDevice));
+  int rc = mfx_rotate_dev(p, dd, B, normalise_dirs, dout, nullptr);
+  if (rc == MFX_OK) {
+    hipError_t e = hipMemcpy(out, dout, sizeof(double) * n_out, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "mfx_rotate: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(dd); (void)hipFree(dout);
+  return rc;
+}
+
+extern "C" int mfx_rotate_cols_dev(const mfx_plan* p, const double* d_dirs, const int32_t* d_cols, int64_t B,
+                                   int normalise_dirs, double* d_out, void* stream) {
+  if (!p || !d_dirs || !d_cols || !d_out || B < 0) return fail(MFX_ERR_ARG, "mfx_rotate_cols_dev: bad argument");
+  if (B == 0) return MFX_OK;
+  if (int rc = require_device(p->t->device)) return rc;
+  const int64_t total = B * p->d.M;
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffff) return fail(MFX_ERR_ARG, "batch too large");
+  hipLaunchKernelGGL(mfx_rotate_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p->t->d, p->d,
+                     d_dirs, d_cols, B, normalise_dirs, d_out);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_rotate_cols(const mfx_plan* p, const double* dirs, const int32_t* cols, int64_t B,
+                               int normalise_dirs, double* out) {
+  if (!p || !dirs || !cols || !out || B < 0) return fail(MFX_ERR_ARG, "mfx_rotate_cols: bad argument");
+  if (B == 0) return MFX_OK;
+  if (int rc = require_device(p->t->device)) return rc;
+  for (int64_t b = 0; b < B; ++b)
+    if (cols[b] < 0 || cols[b] >= p->t->d.N) return fail(MFX_ERR_ARG, "atom index %d out of range", cols[b]);
+  double *dd = nullptr, *dout = nullptr;
+  int* dc = nullptr;
+  HIPCHK(hipMalloc(&dd, sizeof(double) * 3 * B));
+  HIPCHK(hipMalloc(&dc, sizeof(int) * B));
+  HIPCHK(hipMalloc(&dout, sizeof(double) * B * p->d.M));
+  HIPCHK(hipMemcpy(dd, dirs, sizeof(double) * 3 * B, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dc, cols, sizeof(int) * B, hipMemcpyHostToDevice));
+  int rc = mfx_rotate_cols_dev(p, dd, dc, B, normalise_dirs, dout, nullptr);
+  if (rc == MFX_OK) {
+    hipError_t e = hipMemcpy(out, dout, sizeof(double) * B * p->d.M, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "mfx_rotate_cols: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(dd); (void)hipFree(dc); (void)hipFree(dout);
+  return rc;
+}
+
 // entry points not built yet in this translation unit return MFX_ERR_UNSUPPORTED (never a CPU result)
-extern "C" int mfx_rotate(const mfx_plan*, const double*, int64_t, int, double*) {
-  return fail(MFX_ERR_UNSUPPORTED, "mfx_rotate not built yet");
-}
-extern "C" int mfx_rotate_dev(const mfx_plan*, const double*, int64_t, int, double*, void*) {
-  return fail(MFX_ERR_UNSUPPORTED, "mfx_rotate_dev not built yet");
-}
 extern "C" int mfx_solve_exhaustive(const double*, int64_t, int, const int64_t*, int, const double*, double*, int64_t*,
                                     int64_t*, double*, double*) {
   return fail(MFX_ERR_UNSUPPORTED, "mfx_solve_exhaustive not built yet");

@@ -99,3 +99,16 @@ def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None
                                   L.dptr(sc) if sc is not None else None, L.dptr(se) if se is not None else None,
                                   int(E), V, L.dptr(out)))
     return out
+
+
+def rotate_columns_dev(plan, d_dirs, d_cols, normalise=False):
+    """Device-resident single-atom rotation: torch CUDA tensors dirs [B,3] f64, cols [B] i32 -> [B,M] f64."""
+    import torch
+    assert d_dirs.is_cuda and d_dirs.dtype == torch.float64 and d_dirs.is_contiguous()
+    cols = d_cols.to(torch.int32).contiguous()
+    B = d_dirs.shape[0]
+    out = torch.empty((B, plan.M), dtype=torch.float64, device=d_dirs.device)
+    st = torch.cuda.current_stream(d_dirs.device).cuda_stream
+    L.check(L.lib().mfx_rotate_cols_dev(plan.handle(), d_dirs.data_ptr(), cols.data_ptr(), B, int(normalise),
+                                        out.data_ptr(), st))
+    return out
