@@ -20,6 +20,7 @@
 // Rotated dictionaries are never materialised in HBM: per voxel the kernel reads y (M doubles),
 // two directions, and writes num_params doubles.
 #include "mfx_device.h"
+#include "nnls_small.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -45,29 +46,6 @@ struct Cand {
   double score;
   int i, j;
 };
-
-// exact 2-variable NNLS on precomputed scalars, case analysis of mf_utils.py:341-379 / 425-458
-__device__ __forceinline__ void nnls2_exact(double y_sq, double A11, double A12, double A22, double Y1, double Y2,
-                                            double& w0, double& w1, double& res) {
-  const double d1 = A22 * Y1 - A12 * Y2;
-  const double d2 = A11 * Y2 - A12 * Y1;
-  w0 = 0.0;
-  w1 = 0.0;
-  res = y_sq;
-  if (d1 > 0.0 && d2 > 0.0) {
-    const double Det = A11 * A22 - A12 * A12;
-    w0 = d1 / Det;
-    w1 = d2 / Det;
-    res = (res + w0 * w0 * A11 + w1 * w1 * A22 + 2 * (w0 * w1 * A12 - w0 * Y1 - w1 * Y2));
-  } else if (d1 >= 0.0 && d2 <= 0.0) {
-    if (Y1 >= 0.0) { w0 = Y1 / A11; res = res - Y1 * w0; }
-  } else if (d1 <= 0.0 && d2 >= 0.0) {
-    if (Y2 >= 0.0) { w1 = Y2 / A22; res = res - Y2 * w1; }
-  } else if (d1 < 0.0 && d2 < 0.0) {
-    if (Y1 > 0) { w0 = Y1 / A11; res -= Y1 * w0; }
-    else if (Y2 > 0) { w1 = Y2 / A22; res -= Y2 * w1; }
-  }
-}
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll

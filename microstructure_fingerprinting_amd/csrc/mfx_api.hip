@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "fit_k2.hip"
+#include "fit_small.hip"
 #include "rotate.hip"
 #include "mfx_device.h"
 
@@ -261,30 +262,102 @@ static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 200 in this build (got %d)", M);
 }
 
+// ---- extra (voxel-independent) columns of one voxel class: [csf] + [ear_0..ear_{E-1}]
+struct ExtrasHost {
+  ExtrasDev d{};
+  void* dx = nullptr;
+  void* dG = nullptr;
+  int build(int M, int has_csf, int E, const double* sig_csf, const double* sig_ear, bool src_on_device) {
+    const int NX = has_csf + E;
+    d.NX = NX; d.has_csf = has_csf; d.E = E; d.x = nullptr; d.Gxx = nullptr;
+    if (NX == 0) return MFX_OK;
+    if (NX > MFX_NXMAX) return fail(MFX_ERR_UNSUPPORTED, "at most %d CSF+EAR columns are supported (got %d)", MFX_NXMAX, NX);
+    std::vector<double> hc(has_csf ? M : 0), he((size_t)M * E);
+    if (has_csf) {
+      if (!sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
+      if (src_on_device) HIPCHK(hipMemcpy(hc.data(), sig_csf, sizeof(double) * M, hipMemcpyDeviceToHost));
+      else std::memcpy(hc.data(), sig_csf, sizeof(double) * M);
+    }
+    if (E) {
+      if (!sig_ear) return fail(MFX_ERR_ARG, "sig_ear missing");
+      if (src_on_device) HIPCHK(hipMemcpy(he.data(), sig_ear, sizeof(double) * M * E, hipMemcpyDeviceToHost));
+      else std::memcpy(he.data(), sig_ear, sizeof(double) * (size_t)M * E);
+    }
+    std::vector<double> x((size_t)M * NX), G((size_t)NX * NX, 0.0);
+    for (int m = 0; m < M; ++m) {
+      if (has_csf) x[(size_t)m * NX] = hc[m];
+      for (int e = 0; e < E; ++e) x[(size_t)m * NX + has_csf + e] = he[(size_t)m * E + e];
+    }
+    for (int p = 0; p < NX; ++p)
+      for (int q = 0; q < NX; ++q) {
+        double acc = 0.0;  // sequential over rows, as the reference's Gram loops (mf_utils.py:311-319, 517-531)
+        for (int m = 0; m < M; ++m) acc += x[(size_t)m * NX + p] * x[(size_t)m * NX + q];
+        G[(size_t)p * NX + q] = acc;
+      }
+    HIPCHK(hipMalloc(&dx, sizeof(double) * x.size()));
+    HIPCHK(hipMalloc(&dG, sizeof(double) * G.size()));
+    HIPCHK(hipMemcpy(dx, x.data(), sizeof(double) * x.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dG, G.data(), sizeof(double) * G.size(), hipMemcpyHostToDevice));
+    d.x = (const double*)dx;
+    d.Gxx = (const double*)dG;
+    return MFX_OK;
+  }
+  ~ExtrasHost() { (void)hipFree(dx); (void)hipFree(dG); }
+};
+
+static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
+  const int M = a.P.M;
+  const size_t lds = sizeof(double) * (3 * (size_t)M + MFX_NXMAX + 8 + MFX_SWG + 3 * MFX_SWG) + sizeof(long) * MFX_SWG +
+                     sizeof(int) * 2 * (size_t)M;
+  if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "too many measurements (%d)", M);
+  if (a.P.any_bracket) {
+    HIPCHK(hipFuncSetAttribute((const void*)mfx_fit_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mfx_fit_small_kernel<true>, dim3(nvox), dim3(MFX_SWG), lds, st, a);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)mfx_fit_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mfx_fit_small_kernel<false>, dim3(nvox), dim3(MFX_SWG), lds, st, a);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+// one homogeneous voxel class (every voxel: K fascicles, has_csf, has_ear); device pointers
+static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
+                         int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc, int csf_on,
+                         int ear_on, double* d_params, hipStream_t st) {
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  if (nvox == 0) return MFX_OK;
+  if (K + has_csf + has_ear == 0) return MFX_OK;  // mf.py:387-388: rows stay zero
+  if (K <= 1) {
+    FitSmallArgs a{};
+    a.T = p->t->d; a.P = p->d; a.X = X.d;
+    a.Y = d_Y; a.peaks = d_peaks; a.peaks_ld = peaks_ld; a.vox_list = d_list;
+    a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc; a.csf_on = csf_on; a.ear_on = ear_on;
+    a.K = K;
+    return launch_small(a, nvox, st);
+  }
+  if (K == 2 && !has_csf && !has_ear) {
+    FitK2Args a{};
+    a.T = p->t->d; a.P = p->d;
+    a.Y = d_Y; a.peaks = d_peaks; a.peaks_ld = peaks_ld; a.vox_list = d_list;
+    a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc;
+    return launch_k2(a, nvox, st);
+  }
+  return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented yet", K, has_csf, has_ear);
+}
+
 extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int maxfasc, int csf_on,
                                  int ear_on, const double* d_sig_csf, const double* d_sig_ear, int E, int64_t V,
                                  double* d_params_out, void* stream) {
   if (!p || !d_Y || !d_params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: bad argument");
+  if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
   if (V == 0) return MFX_OK;
+  if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
   if (int rc = require_device(p->t->device)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
-  if (maxfasc == 2 && !csf_on && !ear_on) {
-    FitK2Args a{};
-    a.T = p->t->d;
-    a.P = p->d;
-    a.Y = d_Y;
-    a.peaks = d_peaks;
-    a.peaks_ld = 3 * maxfasc;
-    a.vox_list = nullptr;
-    a.params = d_params_out;
-    a.num_params = num_params;
-    a.maxfasc = maxfasc;
-    if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
-    return launch_k2(a, (int)V, st);
-  }
-  (void)d_sig_csf; (void)d_sig_ear; (void)E;
-  return fail(MFX_ERR_UNSUPPORTED, "class (K=%d, csf=%d, ear=%d) not implemented yet", maxfasc, csf_on, ear_on);
+  ExtrasHost X;
+  if (int rc = X.build(p->d.M, csf_on ? 1 : 0, ear_on ? E : 0, d_sig_csf, d_sig_ear, true)) return rc;
+  return fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
+                       csf_on ? 1 : 0, ear_on ? 1 : 0, d_params_out, (hipStream_t)stream);
 }
 
 extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,
@@ -292,51 +365,52 @@ extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* 
                              const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {
   if (!p || !Y || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
   if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large");
   if (int rc = require_device(p->t->device)) return rc;
+  csf_on = csf_on ? 1 : 0;
+  ear_on = ear_on ? 1 : 0;
   const int M = p->d.M;
   const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   std::memset(params_out, 0, sizeof(double) * (size_t)V * num_params);
   if (V == 0) return MFX_OK;
-  // direction check once per batch (the reference checks per voxel, mf_utils.py:1798-1802)
-  for (int64_t v = 0; v < V; ++v)
-    for (int k = 0; k < K[v]; ++k) {
-      const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * k;
+  // bin voxels by class (K, csf, ear); direction check once per batch (the reference checks per
+  // voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
+  std::vector<int> cls[12];
+  for (int64_t v = 0; v < V; ++v) {
+    const int k = K[v];
+    if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
+    const int c = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
+    if ((c && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
+    for (int f = 0; f < k; ++f) {
+      const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
       const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
       if (!(std::fabs(1 - nrm) <= 1e-3))
         return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
     }
-  // bin voxels by class
-  std::vector<int> cls_k2;
-  for (int64_t v = 0; v < V; ++v) {
-    const int c = csf ? (csf[v] != 0) : 0, e = ear ? (ear[v] != 0) : 0;
-    if (K[v] == 2 && !c && !e) cls_k2.push_back((int)v);
-    else if (K[v] + c + e == 0) continue;  // mf.py:387-388: all-zero row
-    else return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented yet", K[v], c, e);
+    cls[k * 4 + c * 2 + e].push_back((int)v);
   }
-  (void)sig_csf; (void)sig_ear; (void)E;
   double *dY = nullptr, *dpk = nullptr, *dpar = nullptr;
   int* dlist = nullptr;
   HIPCHK(hipMalloc(&dY, sizeof(double) * (size_t)V * M));
   HIPCHK(hipMalloc(&dpk, sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1)));
   HIPCHK(hipMalloc(&dpar, sizeof(double) * (size_t)V * num_params));
+  HIPCHK(hipMalloc(&dlist, sizeof(int) * (size_t)V));
   HIPCHK(hipMemcpy(dY, Y, sizeof(double) * (size_t)V * M, hipMemcpyHostToDevice));
   if (maxfasc > 0) HIPCHK(hipMemcpy(dpk, peaks, sizeof(double) * (size_t)V * 3 * maxfasc, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dpar, 0, sizeof(double) * (size_t)V * num_params));
   int rc = MFX_OK;
-  if (!cls_k2.empty()) {
-    HIPCHK(hipMalloc(&dlist, sizeof(int) * cls_k2.size()));
-    HIPCHK(hipMemcpy(dlist, cls_k2.data(), sizeof(int) * cls_k2.size(), hipMemcpyHostToDevice));
-    FitK2Args a{};
-    a.T = p->t->d;
-    a.P = p->d;
-    a.Y = dY;
-    a.peaks = dpk;
-    a.peaks_ld = 3 * maxfasc;
-    a.vox_list = dlist;
-    a.params = dpar;
-    a.num_params = num_params;
-    a.maxfasc = maxfasc;
-    rc = launch_k2(a, (int)cls_k2.size(), nullptr);
+  size_t off = 0;
+  std::vector<ExtrasHost> xs(4);
+  for (int ce = 0; ce < 4 && rc == MFX_OK; ++ce) {
+    if (((ce >> 1) && !csf_on) || ((ce & 1) && !ear_on)) continue;  // class cannot occur
+    rc = xs[ce].build(M, ce >> 1, (ce & 1) ? E : 0, sig_csf, sig_ear, false);
+  }
+  for (int c = 0; c < 12 && rc == MFX_OK; ++c) {
+    if (cls[c].empty()) continue;
+    HIPCHK(hipMemcpy(dlist + off, cls[c].data(), sizeof(int) * cls[c].size(), hipMemcpyHostToDevice));
+    rc = fit_class_dev(p, dY, dpk, 3 * maxfasc, dlist + off, (int)cls[c].size(), c >> 2, (c >> 1) & 1, c & 1, xs[c & 3],
+                       maxfasc, csf_on, ear_on, dpar, nullptr);
+    off += cls[c].size();
   }
   if (rc == MFX_OK) {
     hipError_t e = hipDeviceSynchronize();

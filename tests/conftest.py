@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """When GPU tests are selected, initialise torch's HIP context once, before the C-ABI library
+    creates its own (both share the primary context; doing it up front keeps the order fixed)."""
+    if any("gpu" in it.keywords for it in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass

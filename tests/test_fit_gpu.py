@@ -193,3 +193,114 @@ def test_bad_direction_raises():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed compartment classes (reference MFModel.fit goldens, mf.py:340-461 packing)
+def _maps_from_params(P, maxfasc, csf_on, ear_on, props, DIFF_ear):
+    """MFModelFit.__init__ semantics (mf.py:1068-1157) on flat ROI rows."""
+    out = {"M0": P[:, 0]}
+    for k in range(maxfasc):
+        out["frac_f%d" % k] = P[:, 1 + k]
+    for name, tab in props.items():
+        tot = np.zeros(P.shape[0])
+        for k in range(maxfasc):
+            nu = P[:, 1 + k]
+            pk = tab[P[:, 1 + maxfasc + k].astype(int)] * (nu > 0)
+            tot += nu * pk
+            out["%s_f%d" % (name, k)] = pk
+        out[name + "_tot"] = tot
+    if csf_on:
+        out["frac_csf"] = P[:, 2 * maxfasc + 1]
+    if ear_on:
+        nu_e = P[:, 2 * maxfasc + csf_on + 1]
+        out["frac_ear"] = nu_e
+        out["D_ear"] = DIFF_ear[P[:, 2 * maxfasc + csf_on + 2].astype(int)] * (nu_e > 0)
+    out["MSE"] = P[:, -2]
+    out["R2"] = P[:, -1]
+    return out
+
+
+def _mixed_case():
+    from oracle import oracle as orc
+    d = np.load(os.path.join(G, "fit_cases.npz"))
+    sch = d["sch"]
+    b = (orc.GAMMA_H * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / float(d["T2_csf"])) * np.exp(-b * float(d["DIFF_csf"]))
+    sig_ear = np.stack([np.exp(-sch[:, 6] / float(d["T2_ear"])) * np.exp(-b * x) for x in d["DIFF_ear"]], axis=1)
+    return d, sch, sig_csf, sig_ear
+
+
+@pytest.mark.xfail(reason="K=2 + CSF/EAR epilogues not wired yet", strict=False)
+def test_mixed_classes_reference_golden():
+    """24-voxel ROI fitted by the reference's MFModel.fit: K in {0,1,2} x CSF x EAR (exercises _1, _2, _3,
+    _4up), bracketed protocol rows, one all-zero voxel, one single-active tie voxel."""
+    from microstructure_fingerprinting_amd import engine
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    d, sch, sig_csf, sig_ear = _mixed_case()
+    ms = mfu.init_PGSE_multishell_interp(d["dictionary"], d["sch_ms"], Z)
+    P = engine.fit_batch(ms.plan_for(sch), d["Y"], d["numfasc"], d["csf"], d["ear"], d["peaks"], 2, True, True,
+                         sig_csf, sig_ear, int(d["E"]))
+    maps = _maps_from_params(P, 2, 1, 1, {"rad": d["rad"], "fin": d["fin"]}, d["DIFF_ear"])
+    for name, arr in maps.items():
+        assert np.allclose(arr, d["map_" + name].reshape(-1), rtol=RTOL_W, atol=1e-9), name
+    assert np.all(P[21] == 0)     # K=0, no CSF, no EAR: zeros (mf.py:387-388)
+
+
+def test_k1_reference_golden_and_oracle():
+    from microstructure_fingerprinting_amd import engine
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    d0, sch, sig_csf, sig_ear = _mixed_case()
+    d = np.load(os.path.join(G, "fit_cases_k1.npz"))
+    ms = mfu.init_PGSE_multishell_interp(d0["dictionary"], d0["sch_ms"], Z)
+    V = d["Y"].shape[0]
+    P = engine.fit_batch(ms.plan_for(sch), d["Y"], np.ones(V, int), None, None, d["peaks"], 1, False, False)
+    maps = _maps_from_params(P, 1, 0, 0, {"rad": d0["rad"], "fin": d0["fin"]}, None)
+    for name, arr in maps.items():
+        assert np.allclose(arr, d["map_" + name].reshape(-1), rtol=RTOL_W, atol=1e-12), name
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    z = np.zeros(V, bool)
+    ref = orc.fit_batch(T, sch, d["Y"], np.ones(V, int), z, z, d["peaks"], 1, False, False, None, None, 0)
+    assert np.array_equal(P[:, 2], ref[:, 2]) and np.allclose(P, ref, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("K,c,e", [(1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1), (0, 1, 0), (0, 0, 1), (0, 1, 1)])
+def test_small_classes_vs_oracle(K, c, e):
+    """Every K<=1 class on 40 random voxels (C1 shape: 100 atoms x 60 measurements) against the oracle,
+    homogeneous batches through the device-pointer entry as well."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    sch, dic, rng = synth.make_model("C1")
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    N, E, V = ms.num_subs, 5, 40
+    b = (orc.GAMMA_H * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3e-9)
+    sig_ear = np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * x) for x in np.linspace(0.2e-9, 1.2e-9, E)], axis=1)
+    maxfasc = max(K, 1)
+    peaks = synth.unit_vectors(rng, V)
+    Y = rng.normal(0, 15.0, (V, sch.shape[0]))
+    for v in range(V):
+        comps = []
+        if K:
+            comps.append(orc.interp(sch, peaks[v], T)[:, rng.integers(0, N)])
+        if c:
+            comps.append(sig_csf)
+        if e:
+            comps.append(sig_ear[:, rng.integers(0, E)])
+        nu = rng.dirichlet(np.ones(len(comps)))
+        if v % 7 == 3:
+            nu[rng.integers(0, len(comps))] = 0.0     # missing compartment -> single-active branches
+        Y[v] += 400 * np.stack(comps, 1) @ nu
+    Y[5] = -np.abs(Y[5])                                # nothing fits
+    Kv = np.full(V, K)
+    cm = np.full(V, bool(c)); em = np.full(V, bool(e))
+    ref = orc.fit_batch(T, sch, Y, Kv, cm, em, peaks, maxfasc, bool(c), bool(e), sig_csf if c else None,
+                        sig_ear if e else None, E if e else 0)
+    got = engine.fit_batch(ms.plan_for(sch), Y, Kv, cm, em, peaks, maxfasc, bool(c), bool(e),
+                           sig_csf if c else None, sig_ear if e else None, E if e else 0)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
+    ids = [1 + maxfasc + k for k in range(K)] + ([2 * maxfasc + c + 2] if e else [])
+    assert np.array_equal(got[:, ids], ref[:, ids])
