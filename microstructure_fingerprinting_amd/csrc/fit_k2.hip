@@ -19,6 +19,7 @@
 //            winner, and the voxel's parameters are written.
 // Rotated dictionaries are never materialised in HBM: per voxel the kernel reads y (M doubles),
 // two directions, and writes num_params doubles.
+#pragma once
 #include "mfx_device.h"
 #include "nnls_small.h"
 

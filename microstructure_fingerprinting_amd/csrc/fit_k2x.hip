@@ -1,0 +1,361 @@
+// fit_k2x.hip -- fused per-voxel kernel for two fascicles PLUS voxel-independent compartments:
+//   [N,N,1] (CSF), [N,N,E] (EAR)          -> solve_exhaustive_posweights_3   (mf_utils.py:470-607)
+//   [N,N,1,E] (CSF + EAR)                 -> solve_exhaustive_posweights_4up (mf_utils.py:612-657)
+// Same skeleton as fit_k2.hip (one workgroup per voxel, D1 tile in registers, D2 tiles through LDS, FP64
+// MFMA cross-Gram), but 16-atom chunks and a heavier epilogue: every (i1,i2) accumulator entry is
+// combined with each extra column (3x3 / 4x4 normal equations, feasible-support ranking); the inner
+// products of the rotated atoms with the extra columns are computed once per voxel into a per-workgroup
+// HBM scratch slab and staged through LDS.  Short-listed tuples are re-evaluated with the reference's
+// exact arithmetic (Cramer + explicit residual for _3; Gram-based active-set optimum + explicit residual
+// for _4up, whose reference is the third-party scipy.optimize.nnls).  VALU-bound (the epilogue dominates).
+#pragma once
+#include "fit_small.hip"  // ExtrasDev, mfx_np_sumsq
+#include "mfx_device.h"
+#include "nnls_small.h"
+
+typedef double d4x __attribute__((ext_vector_type(4)));
+
+#define MFX_XWG 512
+#define MFX_XMAXC 256
+#define MFX_XS 16  // stride of the extras dimension in scratch/LDS
+
+struct FitK2XArgs {
+  TablesDev T;
+  PlanDev P;
+  ExtrasDev X;
+  const double* Y;
+  const double* peaks;
+  int peaks_ld;
+  const int* vox_list;
+  double* params;
+  double* ws;  // [gridDim.x][2][NP][MFX_XS] scratch: atom . extra-column inner products
+  int num_params, maxfasc, csf_on, ear_on;
+  int vox_base;  // first voxel (or first vox_list entry) of this launch
+};
+
+struct CandX {
+  double score;
+  int i, j, e, pad;
+};
+
+template <int KSTEPS, bool BRACKET>
+__global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
+  constexpr int MP = KSTEPS * 4;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int M = a.P.M, N = a.T.N, ldn = a.T.ldn, NP = ldn, ntiles = NP >> 4;
+  const int NX = a.X.NX, E = a.X.E, has_csf = a.X.has_csf;
+  const int Kp = 2 + has_csf + (E > 0);
+  const int ntup = (Kp == 3) ? NX : E;  // extra tuples per (i1,i2)
+  const double2* __restrict__ tab = a.T.tab;
+  const int vox = a.vox_list ? a.vox_list[a.vox_base + blockIdx.x] : a.vox_base + blockIdx.x;
+  double* __restrict__ wsA = a.ws + (size_t)blockIdx.x * 2 * NP * MFX_XS;  // [k][n][e]
+
+  double* sB = smem;                              // [2 buf][MP][16]
+  double* s_y = sB + 2 * MP * 16;                 // [MP]
+  double* s_t0 = s_y + MP;                        // [2][MP]
+  double* s_t1 = s_t0 + 2 * MP;                   // [2][MP] (bracket)
+  double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);
+  double* s_dG = s_tG + (BRACKET ? MP : 0);
+  double* s_A11 = s_dG + (BRACKET ? MP : 0);      // [NP] x4
+  double* s_Y1 = s_A11 + NP;
+  double* s_A22 = s_Y1 + NP;
+  double* s_Y2 = s_A22 + NP;
+  double* s_a1x = s_Y2 + NP;                      // [8 waves][16 rows][XS]
+  double* s_a2x = s_a1x + 8 * 16 * MFX_XS;        // [2 buf][16 cols][XS]
+  double* s_Yx = s_a2x + 2 * 16 * MFX_XS;         // [XS]
+  double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
+  double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
+  CandX* s_cand = (CandX*)(s_red + 32);           // [XMAXC]
+  int* s_r0 = (int*)(s_cand + MFX_XMAXC);         // [2][MP]
+  int* s_r1 = s_r0 + 2 * MP;
+  int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);
+
+  const double* __restrict__ yv = a.Y + (size_t)vox * M;
+  const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
+  const double* __restrict__ xx = a.X.x;
+  for (int m = tid; m < MP; m += MFX_XWG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int idx = tid; idx < 2 * MP; idx += MFX_XWG) {
+    const int k = idx / MP, m = idx - k * MP;
+    RowDesc rd;
+    rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;
+    if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
+    s_r0[idx] = rd.r0;
+    s_t0[idx] = rd.t0;
+    if (BRACKET) {
+      s_r1[idx] = rd.r1;
+      s_t1[idx] = rd.t1;
+      if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
+    }
+  }
+  for (int q = tid; q < MFX_XS * MFX_XS; q += MFX_XWG) {
+    const int p = q / MFX_XS, r = q - p * MFX_XS;
+    s_Gxx[q] = (p < NX && r < NX) ? a.X.Gxx[p * NX + r] : 0.0;
+  }
+  if (tid == 0) s_cnt[0] = 0;
+  __syncthreads();
+  if (tid < MFX_XS) {
+    double s = 0.0;
+    if (tid < NX)
+      for (int m = 0; m < M; ++m) s += s_y[m] * xx[(size_t)m * NX + tid];
+    s_Yx[tid] = s;
+  }
+  if (tid == 64) s_red[16] = mfx_np_sumsq(s_y, M);  // _4up: min_obj starts at np.sum(y**2)
+
+  auto elem = [&](int k, int m, int n) -> double {
+    if (BRACKET) {
+      RowDesc rd;
+      rd.r0 = s_r0[k * MP + m]; rd.t0 = s_t0[k * MP + m];
+      rd.r1 = s_r1[k * MP + m]; rd.t1 = s_t1[k * MP + m];
+      return mfx_eval_br(tab, ldn, rd, s_tG[m], s_dG[m], n);
+    } else {
+      return mfx_eval(tab, ldn, s_r0[k * MP + m], s_t0[k * MP + m], n);
+    }
+  };
+
+  // ---- phase 1: column statistics + inner products with the extra columns (sequential over rows)
+  double y_sq_seq = 0.0;
+  for (int m = 0; m < M; ++m) y_sq_seq += s_y[m] * s_y[m];
+  for (int col = tid; col < 2 * NP; col += MFX_XWG) {
+    const int k = col >= NP, n = col - k * NP;
+    double a2 = 0.0, ay = 0.0, ax[MFX_XS];
+#pragma unroll
+    for (int e = 0; e < MFX_XS; ++e) ax[e] = 0.0;
+    if (n < N) {
+      for (int m = 0; m < M; ++m) {
+        const double d = elem(k, m, n);
+        a2 += d * d;
+        ay += s_y[m] * d;
+#pragma unroll
+        for (int e = 0; e < MFX_XS; ++e)
+          if (e < NX) ax[e] += d * xx[(size_t)m * NX + e];
+      }
+    }
+    (k ? s_A22 : s_A11)[n] = a2;
+    (k ? s_Y2 : s_Y1)[n] = ay;
+#pragma unroll
+    for (int e = 0; e < MFX_XS; ++e) wsA[((size_t)k * NP + n) * MFX_XS + e] = ax[e];
+  }
+  __syncthreads();
+  const double y_sq = (Kp == 4) ? s_red[16] : y_sq_seq;
+
+  auto gen_chunk = [&](int ch, int buf) {
+    const int c = tid & 15, m0 = tid >> 4;  // 32 row groups
+    const int n = ch * 16 + c;
+    double* dst = sB + (size_t)buf * (MP * 16) + c;
+    for (int m = m0; m < MP; m += 32) dst[m * 16] = elem(1, m, n);
+    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms
+      const int cc = tid / MFX_XS, e = tid - cc * MFX_XS;
+      s_a2x[(buf * 16 + cc) * MFX_XS + e] = wsA[((size_t)NP + ch * 16 + cc) * MFX_XS + e];
+    }
+  };
+
+  const int nrounds = (ntiles + 7) >> 3;
+  const double eps_abs = 1e-9 * y_sq;
+  double gmax_run = 0.0;
+
+  for (int round = 0; round < nrounds; ++round) {
+    const int rt = round * 8 + wave;
+    const bool rt_valid = rt < ntiles;
+    double afr[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rt * 16 + lc) : 0.0;
+    // stage this wave's A1x rows
+    if (rt_valid)
+      for (int q = lane; q < 16 * MFX_XS; q += 64) s_a1x[wave * 16 * MFX_XS + q] = wsA[((size_t)rt * 16) * MFX_XS + q];
+    double bs[4];
+    int bj[4], be[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bj[r] = -1; be[r] = 0; }
+
+    gen_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < ntiles; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+      if (rt_valid) {
+        const double* bp = sB + (size_t)buf * (MP * 16) + lg * 16 + lc;
+        d4x acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bp[kk * 64], acc, 0, 0, 0);
+        const int j = ch * 16 + lc;
+        if (j < N) {
+          const double A22 = s_A22[j], Y2 = s_Y2[j];
+          const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int il = lg + 4 * r;
+            const int i = rt * 16 + il;
+            if (i < N) {
+              const double A11 = s_A11[i], Y1 = s_Y1[i], A12 = acc[r];
+              const double* a1x = s_a1x + (wave * 16 + il) * MFX_XS;
+              for (int t = 0; t < ntup; ++t) {
+                double s;
+                if (Kp == 3) {
+                  s = score3(A11, A12, a1x[t], A22, a2x[t], s_Gxx[t * MFX_XS + t], Y1, Y2, s_Yx[t]);
+                } else {
+                  const int ce = 1 + t;
+                  const double g[10] = {A11, A12, a1x[0], a1x[ce], A22, a2x[0], a2x[ce], s_Gxx[0], s_Gxx[ce],
+                                        s_Gxx[ce * MFX_XS + ce]};
+                  const double yy[4] = {Y1, Y2, s_Yx[0], s_Yx[ce]};
+                  s = score4(g, yy);
+                }
+                if (s > bs[r]) { bs[r] = s; bj[r] = j; be[r] = t; }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    double lmax = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lmax = fmax(lmax, bs[r]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) s_red[wave] = lmax;
+    __syncthreads();
+    double rmax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) rmax = fmax(rmax, s_red[w]);
+    gmax_run = fmax(gmax_run, rmax);
+    const double thr = gmax_run - eps_abs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (bj[r] >= 0 && bs[r] >= thr) {
+        const int slot = atomicAdd(&s_cnt[0], 1);
+        if (slot < MFX_XMAXC) {
+          s_cand[slot].score = bs[r];
+          s_cand[slot].i = rt * 16 + lg + 4 * r;
+          s_cand[slot].j = bj[r];
+          s_cand[slot].e = be[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- exact re-evaluation of the short list
+  int ncand = s_cnt[0];
+  ncand = ncand > MFX_XMAXC ? MFX_XMAXC : ncand;
+  const double thr_final = gmax_run - eps_abs;
+  __syncthreads();
+  // scratch inside the (now idle) B buffers: 6*XMAXC + 8 + MP doubles must fit in 2*MP*16
+  static_assert(2 * MP * 16 >= 6 * MFX_XMAXC + 8 + MP, "B buffers too small for the exact-stage scratch");
+  double* s_rres = (double*)sB;                  // [XMAXC]
+  long* s_rkey = (long*)(s_rres + MFX_XMAXC);    // [XMAXC]
+  double* s_rw = (double*)(s_rkey + MFX_XMAXC);  // [XMAXC][4]
+  double* s_win = s_rw + 4 * MFX_XMAXC;          // res, w0..w3, key
+  double* s_yrec = s_win + 8;                    // [MP]
+  double res = INFINITY, w[4] = {0.0, 0.0, 0.0, 0.0};
+  long key = -1;
+  if (tid < ncand && s_cand[tid].score >= thr_final) {
+    const int i = s_cand[tid].i, j = s_cand[tid].j, t = s_cand[tid].e;
+    const int c3 = (Kp == 3) ? t : 0, c4 = 1 + t;
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0, a13 = 0.0, a23 = 0.0, a14 = 0.0, a24 = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double d1 = elem(0, m, i), d2 = elem(1, m, j), ym = s_y[m];
+      const double x3 = xx[(size_t)m * NX + c3];
+      a11 += d1 * d1; a22 += d2 * d2; a12 += d1 * d2; y1 += ym * d1; y2 += ym * d2;
+      a13 += d1 * x3; a23 += d2 * x3;
+      if (Kp == 4) { const double x4 = xx[(size_t)m * NX + c4]; a14 += d1 * x4; a24 += d2 * x4; }
+    }
+    if (Kp == 3) {
+      auto explicit_res = [&](const double* ww) {
+        double rr = 0.0;
+        for (int m = 0; m < M; ++m) {
+          const double tt = (ww[0] * elem(0, m, i) + ww[1] * elem(1, m, j) + ww[2] * xx[(size_t)m * NX + c3] - s_y[m]);
+          rr += tt * tt;
+        }
+        return rr;
+      };
+      nnls3_cramer(y_sq, a11, a12, a13, a22, a23, s_Gxx[c3 * MFX_XS + c3], y1, y2, s_Yx[c3], explicit_res, w, res);
+      key = ((long)t * N + i) * N + j;  // scan order of _3: i3 -> i1 -> i2
+    } else {
+      const double g[10] = {a11, a12, a13, a14, a22, a23, a24, s_Gxx[0], s_Gxx[c4], s_Gxx[c4 * MFX_XS + c4]};
+      const double yy[4] = {y1, y2, s_Yx[0], s_Yx[c4]};
+      nnls_gram_subsets(4, g, yy, w);
+      double rr = 0.0;
+      for (int m = 0; m < M; ++m) {
+        const double tt = (w[0] * elem(0, m, i) + w[1] * elem(1, m, j) + w[2] * xx[(size_t)m * NX] + w[3] * xx[(size_t)m * NX + c4] - s_y[m]);
+        rr += tt * tt;
+      }
+      res = rr;
+      key = ((long)i * N + j) * E + t;  // itertools.product order, last index fastest
+    }
+  }
+  if (tid < MFX_XMAXC) {
+    s_rres[tid] = res;
+    s_rkey[tid] = key;
+    s_rw[4 * tid] = w[0]; s_rw[4 * tid + 1] = w[1]; s_rw[4 * tid + 2] = w[2]; s_rw[4 * tid + 3] = w[3];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double br = y_sq, bw[4] = {0.0, 0.0, 0.0, 0.0};  // initial state of the reference: w = 0, indices 0
+    long bk = -1;
+    for (int c = 0; c < ncand; ++c) {
+      const double r = s_rres[c];
+      const long k = s_rkey[c];
+      if (k < 0) continue;
+      if (r < br || (r == br && bk >= 0 && k < bk)) { br = r; bk = k; bw[0] = s_rw[4 * c]; bw[1] = s_rw[4 * c + 1]; bw[2] = s_rw[4 * c + 2]; bw[3] = s_rw[4 * c + 3]; }
+    }
+    s_win[0] = br; s_win[1] = bw[0]; s_win[2] = bw[1]; s_win[3] = bw[2]; s_win[4] = bw[3];
+    ((long*)s_win)[5] = bk;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const double best = s_win[0];
+    const double w0 = s_win[1], w1 = s_win[2], w2 = s_win[3], w3 = s_win[4];
+    const long bk = ((long*)s_win)[5];
+    int bi = 0, bjx = 0, bt = 0;
+    if (bk >= 0) {
+      if (Kp == 3) { bjx = (int)(bk % N); bi = (int)((bk / N) % N); bt = (int)(bk / ((long)N * N)); }
+      else { bt = (int)(bk % E); bjx = (int)((bk / E) % N); bi = (int)(bk / ((long)E * N)); }
+    }
+    const int c3 = (Kp == 3) ? bt : 0, c4 = 1 + bt;
+    double sy = 0.0, sr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      double yr = elem(0, m, bi) * w0 + elem(1, m, bjx) * w1 + xx[(size_t)m * NX + c3] * w2;
+      if (Kp == 4) yr += xx[(size_t)m * NX + c4] * w3;
+      s_yrec[m] = yr;
+      sy += s_y[m];
+      sr += yr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sy += __shfl_xor(sy, o); sr += __shfl_xor(sr, o); }
+    sy /= M; sr /= M;
+    double cyy = 0.0, crr = 0.0, cyr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double da = s_y[m] - sy, db = s_yrec[m] - sr;
+      cyy += da * da; crr += db * db; cyr += da * db;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cyy += __shfl_xor(cyy, o); crr += __shfl_xor(crr, o); cyr += __shfl_xor(cyr, o); }
+    double r2 = 0.0;
+    if (M > 1 && cyy > 0.0 && crr > 0.0) {
+      const double f = (double)(M - 1);
+      double r = (cyr / f) / sqrt(cyy / f) / sqrt(crr / f);
+      r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+      r2 = r * r;
+    }
+    if (lane == 0) {
+      double* out = a.params + (size_t)vox * a.num_params;
+      const double wv[4] = {w0, w1, w2, w3};
+      double M0 = 0.0;
+      for (int k = 0; k < Kp; ++k) M0 += wv[k];
+      double nu[4];
+      for (int k = 0; k < 4; ++k) nu[k] = (fabs(M0) > 0) ? wv[k] / M0 : wv[k];
+      const int i_csf = 2 * a.maxfasc + 1, i_ear = 2 * a.maxfasc + a.csf_on + 1;
+      out[0] = M0;
+      out[1] = nu[0];
+      out[2] = nu[1];
+      out[1 + a.maxfasc] = (double)bi;
+      out[2 + a.maxfasc] = (double)bjx;
+      if (has_csf) out[i_csf] = nu[2];
+      if (E > 0) { out[i_ear] = nu[2 + has_csf]; out[i_ear + 1] = (double)bt; }
+      out[a.num_params - 2] = best / M;
+      out[a.num_params - 1] = r2;
+    }
+  }
+}

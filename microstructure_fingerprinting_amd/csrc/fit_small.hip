@@ -9,6 +9,7 @@
 // closed forms (including _3's explicit residual), and the workgroup takes the lexicographic
 // (residual, scan-order) minimum = the reference's strict-'<' first hit.  HBM-latency/launch bound;
 // per voxel it reads y and one direction and writes num_params doubles.
+#pragma once
 #include "mfx_device.h"
 #include "nnls_small.h"
 

@@ -16,6 +16,7 @@
 
 #include "fit_k2.hip"
 #include "fit_small.hip"
+#include "fit_k2x.hip"
 #include "rotate.hip"
 #include "mfx_device.h"
 
@@ -321,6 +322,42 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   return MFX_OK;
 }
 
+static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP) {
+  const size_t MP = (size_t)ksteps * 4;
+  size_t dbl = 2 * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + 8 * 16 * MFX_XS +
+               2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 32;
+  return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
+}
+
+template <int KSTEPS, bool BRACKET>
+static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
+  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn);
+  if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
+  auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // per-workgroup scratch slab: launch in chunks so the slab stays modest
+  const int chunk = 2048;
+  const size_t slab = (size_t)2 * a.T.ldn * MFX_XS;
+  double* ws = nullptr;
+  HIPCHK(hipMallocAsync((void**)&ws, sizeof(double) * slab * std::min(chunk, nvox), st));
+  a.ws = ws;
+  for (int base = 0; base < nvox; base += chunk) {
+    a.vox_base = base;
+    hipLaunchKernelGGL(kern, dim3(std::min(chunk, nvox - base)), dim3(MFX_XWG), lds, st, a);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipFreeAsync(ws, st));
+  return MFX_OK;
+}
+
+static int launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
+  const int M = a.P.M;
+  const bool br = a.P.any_bracket != 0;
+  if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
+  if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
+  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernels support M <= 200 in this build (got %d)", M);
+}
+
 // one homogeneous voxel class (every voxel: K fascicles, has_csf, has_ear); device pointers
 static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
                          int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc, int csf_on,
@@ -343,7 +380,14 @@ static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_p
     a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc;
     return launch_k2(a, nvox, st);
   }
-  return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented yet", K, has_csf, has_ear);
+  if (K == 2) {
+    FitK2XArgs a{};
+    a.T = p->t->d; a.P = p->d; a.X = X.d;
+    a.Y = d_Y; a.peaks = d_peaks; a.peaks_ld = peaks_ld; a.vox_list = d_list;
+    a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc; a.csf_on = csf_on; a.ear_on = ear_on;
+    return launch_k2x(a, nvox, st);
+  }
+  return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented", K, has_csf, has_ear);
 }
 
 extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int maxfasc, int csf_on,

@@ -93,3 +93,82 @@ __device__ __forceinline__ double score3(double a11, double a12, double a13, dou
   if (det > 1e-12 * (a11 * a22 * a33) && D1 >= 0.0 && D2 >= 0.0 && D3 >= 0.0) return (y1 * D1 + y2 * D2 + y3 * D3) / det;
   return fmax(score2(a11, a12, a22, y1, y2), fmax(score2(a11, a13, a33, y1, y3), score2(a22, a23, a33, y2, y3)));
 }
+
+// 4x4 SPD solve by elimination; returns false if a pivot is (numerically) non-positive
+__device__ __forceinline__ bool solve4_spd(const double g[10] /* a11 a12 a13 a14 a22 a23 a24 a33 a34 a44 */,
+                                           const double y[4], double w[4]) {
+  const double a11 = g[0], a12 = g[1], a13 = g[2], a14 = g[3], a22 = g[4], a23 = g[5], a24 = g[6], a33 = g[7],
+               a34 = g[8], a44 = g[9];
+  if (!(a11 > 0.0)) return false;
+  const double i1 = 1.0 / a11;
+  const double l21 = a12 * i1, l31 = a13 * i1, l41 = a14 * i1;
+  const double b22 = a22 - l21 * a12, b23 = a23 - l21 * a13, b24 = a24 - l21 * a14;
+  const double b33 = a33 - l31 * a13, b34 = a34 - l31 * a14, b44 = a44 - l41 * a14;
+  const double y2 = y[1] - l21 * y[0], y3 = y[2] - l31 * y[0], y4 = y[3] - l41 * y[0];
+  if (!(b22 > 1e-10 * a22)) return false;
+  const double i2 = 1.0 / b22;
+  const double l32 = b23 * i2, l42 = b24 * i2;
+  const double c33 = b33 - l32 * b23, c34 = b34 - l32 * b24, c44 = b44 - l42 * b24;
+  const double z3 = y3 - l32 * y2, z4 = y4 - l42 * y2;
+  if (!(c33 > 1e-10 * a33)) return false;
+  const double l43 = c34 / c33;
+  const double d44 = c44 - l43 * c34;
+  const double v4 = z4 - l43 * z3;
+  if (!(d44 > 1e-10 * a44)) return false;
+  w[3] = v4 / d44;
+  w[2] = (z3 - c34 * w[3]) / c33;
+  w[1] = (y2 - b23 * w[2] - b24 * w[3]) * i2;
+  w[0] = (y[0] - a12 * w[1] - a13 * w[2] - a14 * w[3]) * i1;
+  return true;
+}
+
+// NNLS optimum (score = y'Aw) of a 4-column system given its Gram; ranking only
+__device__ __forceinline__ double score4(const double g[10], const double y[4]) {
+  double w[4];
+  if (solve4_spd(g, y, w) && w[0] >= 0.0 && w[1] >= 0.0 && w[2] >= 0.0 && w[3] >= 0.0)
+    return w[0] * y[0] + w[1] * y[1] + w[2] * y[2] + w[3] * y[3];
+  // support has at most 3 columns: best of the four 3-subsets (each falls back to pairs/singles itself)
+  const double s123 = score3(g[0], g[1], g[2], g[4], g[5], g[7], y[0], y[1], y[2]);
+  const double s124 = score3(g[0], g[1], g[3], g[4], g[6], g[9], y[0], y[1], y[3]);
+  const double s134 = score3(g[0], g[2], g[3], g[7], g[8], g[9], y[0], y[2], y[3]);
+  const double s234 = score3(g[4], g[5], g[6], g[7], g[8], g[9], y[1], y[2], y[3]);
+  return fmax(fmax(s123, s124), fmax(s134, s234));
+}
+
+// Exact-stage NNLS for n <= 4 columns from a sequentially summed Gram: the support with the largest
+// y'A_S w_S among supports whose unconstrained solution is non-negative (= the NNLS optimum that
+// scipy.optimize.nnls reaches at mf_utils.py:640).  g: upper triangle row-major (n(n+1)/2), w out.
+__device__ inline void nnls_gram_subsets(int n, const double* g, const double* y, double* w) {
+  auto G = [&](int p, int q) { if (p > q) { int t = p; p = q; q = t; } return g[p * n - p * (p - 1) / 2 + (q - p)]; };
+  double best = 0.0;
+  for (int k = 0; k < n; ++k) w[k] = 0.0;
+  for (int mask = 1; mask < (1 << n); ++mask) {
+    int idx[4], c = 0;
+    for (int k = 0; k < n; ++k) if (mask & (1 << k)) idx[c++] = k;
+    double A[4][5];
+    for (int p = 0; p < c; ++p) { for (int q = 0; q < c; ++q) A[p][q] = G(idx[p], idx[q]); A[p][4] = y[idx[p]]; }
+    bool ok = true;
+    for (int p = 0; p < c && ok; ++p) {  // Gaussian elimination (SPD: no pivoting)
+      if (!(A[p][p] > 1e-13 * G(idx[p], idx[p]))) { ok = false; break; }
+      for (int r = p + 1; r < c; ++r) {
+        const double f = A[r][p] / A[p][p];
+        for (int q = p; q < c; ++q) A[r][q] -= f * A[p][q];
+        A[r][4] -= f * A[p][4];
+      }
+    }
+    if (!ok) continue;
+    double ws[4];
+    for (int p = c - 1; p >= 0; --p) {
+      double t = A[p][4];
+      for (int q = p + 1; q < c; ++q) t -= A[p][q] * ws[q];
+      ws[p] = t / A[p][p];
+    }
+    double sc = 0.0;
+    for (int p = 0; p < c; ++p) { if (!(ws[p] >= 0.0)) ok = false; sc += ws[p] * y[idx[p]]; }
+    if (ok && sc > best) {
+      best = sc;
+      for (int k = 0; k < n; ++k) w[k] = 0.0;
+      for (int p = 0; p < c; ++p) w[idx[p]] = ws[p];
+    }
+  }
+}

@@ -4,6 +4,7 @@
 // rotate_atom (mf_utils.py:1423-1426) for B directions at once.  The fused fit kernels never call
 // this (they generate rotated atoms on the fly); it backs the drop-in mf_utils API and synthetic
 // data generation.  HBM-write bound: B*M*N*8 bytes out, table reads served from L2.
+#pragma once
 #include "mfx_device.h"
 
 #define MFX_ROT_ROWS 16
