@@ -18,6 +18,7 @@
 #include "fit_small.hip"
 #include "fit_k2x.hip"
 #include "rotate.hip"
+#include "solve_generic.hip"
 #include "mfx_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -541,8 +542,66 @@ extern "C" int mfx_rotate_cols(const mfx_plan* p, const double* dirs, const int3
   return rc;
 }
 
-// entry points not built yet in this translation unit return MFX_ERR_UNSUPPORTED (never a CPU result)
-extern "C" int mfx_solve_exhaustive(const double*, int64_t, int, const int64_t*, int, const double*, double*, int64_t*,
-                                    int64_t*, double*, double*) {
-  return fail(MFX_ERR_UNSUPPORTED, "mfx_solve_exhaustive not built yet");
+// ---------------------------------------------------------------------------------------------
+// explicit-dictionary solver
+extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const int64_t* dicsizes, int Kp, const double* y,
+                                    double* w, int64_t* sub, int64_t* tot, double* min_obj, double* y_rec) {
+  if (!A || !dicsizes || !y || !w || !sub || !tot || !min_obj || !y_rec || M < 1 || Kp < 1)
+    return fail(MFX_ERR_ARG, "mfx_solve_exhaustive: bad argument");
+  if (Kp > MFX_GK) return fail(MFX_ERR_UNSUPPORTED, "at most %d sub-dictionaries are supported (got %d)", MFX_GK, Kp);
+  if (int rc = require_device(0)) return rc;
+  SolveArgs a{};
+  long Ntot = 0, ntup = 1;
+  for (int k = 0; k < Kp; ++k) {
+    if (dicsizes[k] < 1) return fail(MFX_ERR_ARG, "All entries of dicsizes should be > 0");
+    a.sizes[k] = dicsizes[k];
+    a.start[k] = Ntot;
+    Ntot += dicsizes[k];
+    if (ntup > (1L << 40) / dicsizes[k]) return fail(MFX_ERR_UNSUPPORTED, "too many index tuples for the explicit solver");
+    ntup *= dicsizes[k];
+  }
+  if (lda < Ntot) return fail(MFX_ERR_ARG, "lda (%lld) < number of columns (%ld)", (long long)lda, Ntot);
+  if (Ntot > 30000) return fail(MFX_ERR_UNSUPPORTED, "explicit solver supports up to 30000 columns (got %ld)", Ntot);
+  a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
+  a.nblocks = (int)std::min<long>(8192, (ntup + 255) / 256);
+  std::vector<double> Ac((size_t)M * Ntot);
+  for (int k = 0; k < M; ++k) std::memcpy(&Ac[(size_t)k * Ntot], A + (size_t)k * lda, sizeof(double) * Ntot);
+  double *dA = nullptr, *dy = nullptr, *dG = nullptr, *dAty = nullptr, *dysq = nullptr, *dbs = nullptr, *dw = nullptr,
+         *dobj = nullptr, *dyrec = nullptr;
+  long *dbt = nullptr, *dsub = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(dA); (void)hipFree(dy); (void)hipFree(dG); (void)hipFree(dAty); (void)hipFree(dysq); (void)hipFree(dbs);
+    (void)hipFree(dw); (void)hipFree(dobj); (void)hipFree(dyrec); (void)hipFree(dbt); (void)hipFree(dsub);
+  };
+#define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MFX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } } while (0)
+  SCHK(hipMalloc(&dA, sizeof(double) * Ac.size()));
+  SCHK(hipMalloc(&dy, sizeof(double) * M));
+  SCHK(hipMalloc(&dG, sizeof(double) * (size_t)Ntot * Ntot));
+  SCHK(hipMalloc(&dAty, sizeof(double) * Ntot));
+  SCHK(hipMalloc(&dysq, sizeof(double) * 2));
+  SCHK(hipMalloc(&dbs, sizeof(double) * a.nblocks));
+  SCHK(hipMalloc(&dbt, sizeof(long) * a.nblocks));
+  SCHK(hipMalloc(&dw, sizeof(double) * MFX_GK));
+  SCHK(hipMalloc(&dsub, sizeof(long) * MFX_GK));
+  SCHK(hipMalloc(&dobj, sizeof(double)));
+  SCHK(hipMalloc(&dyrec, sizeof(double) * M));
+  SCHK(hipMemcpy(dA, Ac.data(), sizeof(double) * Ac.size(), hipMemcpyHostToDevice));
+  SCHK(hipMemcpy(dy, y, sizeof(double) * M, hipMemcpyHostToDevice));
+  a.A = dA; a.y = dy; a.G = dG; a.Aty = dAty; a.ysq = dysq; a.blk_score = dbs; a.blk_tuple = dbt;
+  a.w = dw; a.sub = dsub; a.minobj = dobj; a.yrec = dyrec;
+  const long work = Ntot * Ntot + Ntot + 2;
+  hipLaunchKernelGGL(mfx_gram_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, nullptr, a);
+  hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, nullptr, a);
+  hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, nullptr, a);
+  SCHK(hipGetLastError());
+  SCHK(hipDeviceSynchronize());
+  std::vector<long> hsub(MFX_GK);
+  SCHK(hipMemcpy(w, dw, sizeof(double) * Kp, hipMemcpyDeviceToHost));
+  SCHK(hipMemcpy(hsub.data(), dsub, sizeof(long) * Kp, hipMemcpyDeviceToHost));
+  SCHK(hipMemcpy(min_obj, dobj, sizeof(double), hipMemcpyDeviceToHost));
+  SCHK(hipMemcpy(y_rec, dyrec, sizeof(double) * M, hipMemcpyDeviceToHost));
+#undef SCHK
+  for (int k = 0; k < Kp; ++k) { sub[k] = hsub[k]; tot[k] = a.start[k] + hsub[k]; }
+  cleanup();
+  return MFX_OK;
 }
