@@ -111,6 +111,9 @@ int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const int64_t* dic
  * (valid after the stream has been synchronised); < 0 if unavailable.              */
 double mfx_last_kernel_ms(void);
 void mfx_set_profiling(int enabled);
+/* Diagnostic builds only (-DMFX_STAMPS): device buffer [grid x 16] of s_memtime stamps written by the
+ * K=2 kernel at its phase boundaries; a no-op in the shipped build.                                */
+void mfx_debug_set_stamps(void* dev_ptr);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ EXPORTS = [
     "mfx_tables_create", "mfx_tables_destroy", "mfx_tables_num_atoms",
     "mfx_plan_create_multishell", "mfx_plan_create_explicit", "mfx_plan_destroy",
     "mfx_rotate", "mfx_rotate_dev", "mfx_rotate_cols", "mfx_rotate_cols_dev", "mfx_fit_batch", "mfx_fit_batch_dev",
-    "mfx_solve_exhaustive", "mfx_last_kernel_ms", "mfx_set_profiling",
+    "mfx_solve_exhaustive", "mfx_last_kernel_ms", "mfx_set_profiling", "mfx_debug_set_stamps",
 ]
 
 
@@ -64,6 +64,8 @@ def lib():
     L.mfx_last_kernel_ms.restype = C.c_double
     L.mfx_set_profiling.argtypes = [C.c_int]
     L.mfx_set_profiling.restype = None
+    L.mfx_debug_set_stamps.argtypes = [vp]
+    L.mfx_debug_set_stamps.restype = None
     _lib = L
     return L
 

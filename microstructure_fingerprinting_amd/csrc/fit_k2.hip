@@ -20,6 +20,8 @@
 // Rotated dictionaries are never materialised in HBM: per voxel the kernel reads y (M doubles),
 // two directions, and writes num_params doubles.
 #pragma once
+#include <type_traits>
+
 #include "mfx_device.h"
 #include "nnls_small.h"
 
@@ -41,7 +43,14 @@ struct FitK2Args {
   int num_params;
   int maxfasc;
   int csf_on, ear_on;
+  unsigned long long* stamps;  // diagnostic builds only: [gridDim.x][16] s_memtime stamps (null otherwise)
 };
+
+#ifdef MFX_STAMPS
+#define MFX_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFX_STAMP(i) do { } while (0)
+#endif
 
 struct Cand {
   double score;
@@ -59,9 +68,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int KSTEPS, bool BRACKET>
+template <int I, int N, typename F>
+__device__ __forceinline__ void mfx_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    mfx_static_for<I + 1, N>(f);
+  }
+}
+
+// PIPE: software-pipelined chunk loop -- the generation of the next D2 chunk and the pair scan of the
+// previous chunk's accumulators are sliced into the MFMA k-loop of the current chunk, so that every
+// wave issues an MFMA every ~130 cycles without VALU-only or load-latency phases.
+template <int KSTEPS, bool BRACKET, bool PIPE>
 __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   constexpr int MP = KSTEPS * 4;  // padded measurement count
+  constexpr int MPS = ((MP + 15) / 16) * 16;  // rows of one LDS D2 tile (lets the pipelined writer skip a bounds test)
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
@@ -72,8 +93,8 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
 
   // ---- LDS carve-up
-  double* sB = smem;                            // [2 buf][2 tile][MP][16]
-  double* s_y = sB + 2 * 2 * MP * 16;           // [MP]
+  double* sB = smem;                            // [2 buf][2 tile][MPS][16]
+  double* s_y = sB + 2 * 2 * MPS * 16;          // [MP]
   double* s_t0 = s_y + MP;                      // [2][MP]
   double* s_t1 = s_t0 + 2 * MP;                 // [2][MP] (bracket only)
   double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);  // [MP]
@@ -82,12 +103,15 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   double* s_Y1 = s_A11 + NP;
   double* s_A22 = s_Y1 + NP;
   double* s_Y2 = s_A22 + NP;
-  double* s_red = s_Y2 + NP;                    // [16] scratch
+  double* s_S2 = s_Y2 + NP;                     // [NP] single-atom scores of dictionary 2
+  double* s_S1 = s_S2 + NP;                     // [NP] single-atom scores of dictionary 1
+  double* s_red = s_S1 + NP;                    // [16] scratch
   Cand* s_cand = (Cand*)(s_red + 16);           // [MFX_MAXC]
   int* s_r0 = (int*)(s_cand + MFX_MAXC);        // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;                    // [2][MP] (bracket only)
   int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);   // [4] counters
 
+  MFX_STAMP(0);
   // ---- phase 0: y, descriptors
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
@@ -119,6 +143,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     }
   };
 
+  MFX_STAMP(1);
   // ---- phase 1: column statistics, reference order (mf_utils.py:307-325), y_sq likewise
   double y_sq = 0.0;
   for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
@@ -134,6 +159,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     }
     (k ? s_A22 : s_A11)[n] = a2;
     (k ? s_Y2 : s_Y1)[n] = ay;
+    (k ? s_S2 : s_S1)[n] = (n < N && ay > 0.0) ? (ay * ay) / a2 : 0.0;
   }
   __syncthreads();
 
@@ -141,7 +167,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   auto gen_chunk = [&](int ch, int buf) {
     const int c = tid & 31, m0 = tid >> 5;
     const int n = ch * 32 + c;
-    double* dst = sB + (size_t)buf * (2 * MP * 16) + (c >> 4) * (MP * 16) + (c & 15);
+    double* dst = sB + (size_t)buf * (2 * MPS * 16) + (c >> 4) * (MPS * 16) + (c & 15);
     if (n < NP) {
 #pragma unroll 4
       for (int m = m0; m < MP; m += 16) dst[m * 16] = elem(1, m, n);
@@ -150,6 +176,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     }
   };
 
+  MFX_STAMP(2);
   const int nchunks = (ntiles + 1) >> 1;
   const int nrounds = (ntiles + 7) >> 3;
   const double eps_abs = 1e-9 * y_sq;
@@ -163,69 +190,162 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rt * 16 + lc) : 0.0;
     // per-lane row statistics (rows lg + 4r of the tile)
-    double A11r[4], Y1r[4], s1r[4];
+    constexpr bool ROWS_IN_LDS = PIPE && !BRACKET;  // pipelined path re-reads them from LDS (saves 24 VGPRs)
+    double A11r[ROWS_IN_LDS ? 1 : 4], Y1r[ROWS_IN_LDS ? 1 : 4], s1r[ROWS_IN_LDS ? 1 : 4];
     bool rowok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = (rt_valid ? rt : 0) * 16 + lg + 4 * r;
-      A11r[r] = s_A11[i];
-      Y1r[r] = s_Y1[i];
       rowok[r] = rt_valid && (i < N);
-      s1r[r] = (rowok[r] && Y1r[r] > 0.0) ? (Y1r[r] * Y1r[r]) / A11r[r] : 0.0;
+      if constexpr (!ROWS_IN_LDS) {
+        A11r[r] = s_A11[i];
+        Y1r[r] = s_Y1[i];
+        s1r[r] = s_S1[i];
+      }
     }
     double bp[4], bq[4];
     int bj[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bp[r] = 0.0; bq[r] = 1.0; bj[r] = -1; }
 
+    // pair scan of one accumulator entry (row r of the lane, column j)
+    auto scan_one = [&](double A12, int r, int j, bool colok, double A22, double Y2, double s2) {
+      double A11v, Y1v, s1v;
+      if constexpr (ROWS_IN_LDS) {
+        const int i = (rt_valid ? rt : 0) * 16 + lg + 4 * r;
+        A11v = s_A11[i]; Y1v = s_Y1[i]; s1v = s_S1[i];
+      } else {
+        A11v = A11r[r]; Y1v = Y1r[r]; s1v = s1r[r];
+      }
+      const double d1 = fma(-A12, Y2, A22 * Y1v);
+      const double d2 = fma(-A12, Y1v, A11v * Y2);
+      const double pd = A11v * A22;
+      const double Det = fma(-A12, A12, pd);
+      const double num = fma(Y2, d2, Y1v * d1);
+      // (numerically) collinear atom pairs carry no two-atom information: rank them by their
+      // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
+      const bool both = (d1 > 0.0) & (d2 > 0.0) & (Det > MFX_DET_REL * pd);  // bitwise: no short-circuit branches
+      const double smax = fmax(s1v, s2);
+      double p = both ? num : smax;
+      const double q = both ? Det : 1.0;
+      p = (colok & rowok[r]) ? p : 0.0;
+      const bool better = p * bq[r] > bp[r] * q;
+      bp[r] = better ? p : bp[r];
+      bq[r] = better ? q : bq[r];
+      bj[r] = better ? j : bj[r];
+    };
+
+    if (round == 0) MFX_STAMP(3);
     gen_chunk(0, 0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
-      if (rt_valid) {
-        const double* b0p = sB + (size_t)buf * (2 * MP * 16) + lg * 16 + lc;
-        const double* b1p = b0p + MP * 16;
+    if (round == 0) MFX_STAMP(4);
+    if constexpr (PIPE && !BRACKET) {
+      constexpr int NEL = (MP + 15) / 16;                              // D2 elements per thread per chunk
+      constexpr int GS = (KSTEPS - 5) / NEL > 0 ? (KSTEPS - 5) / NEL : 1;  // k-steps between two element loads
+      constexpr int GD = 4;                                            // load -> use distance in k-steps
+      constexpr int SU = (KSTEPS - 2) / 8 > 0 ? (KSTEPS - 2) / 8 : 1;  // k-steps between two scan units
+      static_assert(GS * (NEL - 1) + GD < KSTEPS, "generation slices do not fit in the k-loop");
+      static_assert(SU * 7 + 2 < KSTEPS, "scan slices do not fit in the k-loop");
+      const int gc = tid & 31, gm0 = tid >> 5;
+      const int* gr = s_r0 + MP;       // direction-1 descriptors
+      const double* gt = s_t0 + MP;
+      d4 accP0 = {0, 0, 0, 0}, accP1 = {0, 0, 0, 0};
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const int n_next = min((ch + 1) * 32 + gc, NP - 1);
+        double* gdst = sB + (size_t)(buf ^ 1) * (2 * MPS * 16) + (gc >> 4) * (MPS * 16) + (gc & 15);
+        const double2* gsrc = tab + n_next;
+        const double* b0p = sB + (size_t)buf * (2 * MPS * 16) + lg * 16 + lc;
+        const double* b1p = b0p + MPS * 16;
+        // column statistics of the PREVIOUS chunk (scanned during this chunk's MFMAs)
+        const int jp0 = (ch - 1) * 32 + lc, jp1 = jp0 + 16;
+        const bool okp0 = ch > 0 && jp0 < N, okp1 = ch > 0 && jp1 < N;
+        const int jq0 = okp0 ? jp0 : 0, jq1 = okp1 ? jp1 : 0;
+        const double A22p0 = s_A22[jq0], Y2p0 = s_Y2[jq0], S2p0 = s_S2[jq0];
+        const double A22p1 = s_A22[jq1], Y2p1 = s_Y2[jq1], S2p1 = s_S2[jq1];
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        double2 gl[3];
+        double gtv[3];
+        // B operands are read from LDS PD k-steps ahead of the MFMA that consumes them (the LDS latency
+        // is longer than the ~130-cycle MFMA issue interval of one wave)
+        constexpr int PD = 3;
+        double bb0[PD + 1], bb1[PD + 1];
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-          const double b0 = b0p[kk * 64];
-          const double b1 = b1p[kk * 64];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b1, acc1, 0, 0, 0);
-        }
-        // pair scan on the two accumulator tiles
+        for (int q = 0; q < PD; ++q) { bb0[q] = b0p[q * 64]; bb1[q] = b1p[q * 64]; }
+        mfx_static_for<0, KSTEPS>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value;
+          // (the whole body is branch-free: idle waves of the ragged last round multiply zeros, the
+          // last chunk generates a clamped dummy successor, rows beyond MP land in the tile's padding)
+          {
+            if constexpr (kk + PD < KSTEPS) {
+              bb0[(kk + PD) % (PD + 1)] = b0p[(kk + PD) * 64];
+              bb1[(kk + PD) % (PD + 1)] = b1p[(kk + PD) * 64];
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb0[kk % (PD + 1)], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb1[kk % (PD + 1)], acc1, 0, 0, 0);
+          }
+          // slice of the next chunk's generation: issue the load of element p ...
+          if constexpr (kk % GS == 0 && kk / GS < NEL) {
+            constexpr int p = kk / GS;
+            const int m = min(gm0 + 16 * p, MP - 1);
+            gtv[p % 3] = gt[m];
+            gl[p % 3] = gsrc[(size_t)gr[m] * ldn];
+          }
+          // ... and GD k-steps later turn it into a D2 entry in the other LDS buffer
+          if constexpr (kk >= GD && (kk - GD) % GS == 0 && (kk - GD) / GS < NEL) {
+            constexpr int p = (kk - GD) / GS;
+            gdst[(gm0 + 16 * p) * 16] = gl[p % 3].y * gtv[p % 3] + gl[p % 3].x;
+          }
+          // slice of the previous chunk's pair scan (chunk -1 does not exist: okp* are false then)
+          if constexpr (kk >= 2 && (kk - 2) % SU == 0 && (kk - 2) / SU < 8) {
+            constexpr int u = (kk - 2) / SU;
+            if constexpr (u < 4) scan_one(accP0[u & 3], u & 3, jp0, okp0, A22p0, Y2p0, S2p0);
+            else scan_one(accP1[u & 3], u & 3, jp1, okp1, A22p1, Y2p1, S2p1);
+          }
+        });
+        accP0 = acc0;
+        accP1 = acc1;
+        __syncthreads();
+      }
+      {  // scan of the last chunk
+        const int j0 = (nchunks - 1) * 32 + lc, j1 = j0 + 16;
+        const bool ok0 = j0 < N, ok1 = j1 < N;
+        const int q0 = ok0 ? j0 : 0, q1 = ok1 ? j1 : 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const d4 acc = t ? acc1 : acc0;
-          const int j = ch * 32 + t * 16 + lc;
-          const bool colok = j < N;
-          const double A22 = s_A22[j < NP ? j : 0], Y2 = s_Y2[j < NP ? j : 0];
-          const double s2 = (colok && Y2 > 0.0) ? (Y2 * Y2) / A22 : 0.0;
+        for (int r = 0; r < 4; ++r) scan_one(accP0[r], r, j0, ok0, s_A22[q0], s_Y2[q0], s_S2[q0]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double A12 = acc[r];
-            const double d1 = fma(-A12, Y2, A22 * Y1r[r]);
-            const double d2 = fma(-A12, Y1r[r], A11r[r] * Y2);
-            const double pd = A11r[r] * A22;
-            const double Det = fma(-A12, A12, pd);
-            const double num = fma(Y2, d2, Y1r[r] * d1);
-            // (numerically) collinear atom pairs carry no two-atom information: rank them by their
-            // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
-            const bool both = (d1 > 0.0) && (d2 > 0.0) && (Det > MFX_DET_REL * pd);
-            const double smax = fmax(s1r[r], s2);
-            double p = both ? num : smax;
-            const double q = both ? Det : 1.0;
-            p = (colok && rowok[r]) ? p : 0.0;
-            const bool better = p * bq[r] > bp[r] * q;
-            bp[r] = better ? p : bp[r];
-            bq[r] = better ? q : bq[r];
-            bj[r] = better ? j : bj[r];
+        for (int r = 0; r < 4; ++r) scan_one(accP1[r], r, j1, ok1, s_A22[q1], s_Y2[q1], s_S2[q1]);
+      }
+    } else {
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
+        if (rt_valid) {
+          const double* b0p = sB + (size_t)buf * (2 * MPS * 16) + lg * 16 + lc;
+          const double* b1p = b0p + MPS * 16;
+          d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+          for (int kk = 0; kk < KSTEPS; ++kk) {
+            const double b0 = b0p[kk * 64];
+            const double b1 = b1p[kk * 64];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b1, acc1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const d4 acc = t ? acc1 : acc0;
+            const int j = ch * 32 + t * 16 + lc;
+            const bool colok = j < N;
+            const int jq = colok ? j : 0;
+            const double A22 = s_A22[jq], Y2 = s_Y2[jq], s2 = s_S2[jq];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scan_one(acc[r], r, j, colok, A22, Y2, s2);
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
+    if (round == 0) MFX_STAMP(5);
     // ---- round end: short-list by interval: a candidate stays if its upper bound reaches the best
     // lower bound seen so far.  Bounds: eps_abs (formula/rounding differences between the fraction
     // form and the reference's expression) plus the conditioning-dependent error of num/Det.
@@ -237,7 +357,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       er[r] = 0.0;
       if (bj[r] >= 0) {
         sc[r] = bp[r] / bq[r];
-        const double pd = A11r[r] * s_A22[bj[r]];
+        const double pd = s_A11[(rt_valid ? rt : 0) * 16 + lg + 4 * r] * s_A22[bj[r]];
         er[r] = (bq[r] == 1.0) ? 0.0 : sc[r] * (MFX_A12_REL * pd / bq[r]);
         llb = fmax(llb, sc[r] - er[r]);
       }
@@ -260,9 +380,11 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
         }
       }
     }
+    if (round == 0) MFX_STAMP(9);
     __syncthreads();
   }
 
+  MFX_STAMP(6);
   // ---- phase 3: exact re-evaluation of the short list (reference arithmetic and order)
   // exact (res, w) of one pair: sequential sums over the measurements as mf_utils.py:307-325, then
   // the case analysis of mf_utils.py:341-379
@@ -345,6 +467,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     }
     block_argmin(res, idx, w0, w1);
   }
+  MFX_STAMP(7);
   if (wave == 0) {
     const double best = s_win[0], w0 = s_win[1], w1 = s_win[2];
     const long bidx = ((long*)s_win)[3];
@@ -393,4 +516,5 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       out[a.num_params - 1] = r2;
     }
   }
+  MFX_STAMP(8);
 }

@@ -231,22 +231,31 @@ extern "C" void mfx_plan_destroy(mfx_plan* p) {
 // kernel dispatch
 static size_t k2_lds_bytes(int ksteps, bool bracket, int NP) {
   const size_t MP = (size_t)ksteps * 4;
-  size_t dbl = 2 * 2 * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + 16;
+  const size_t MPS = (MP + 15) / 16 * 16;
+  size_t dbl = 2 * 2 * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 16;
   size_t bytes = dbl * 8 + sizeof(Cand) * MFX_MAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
   return bytes;
 }
 
-template <int KSTEPS, bool BRACKET>
+static unsigned long long* g_stamps = nullptr;
+extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
+static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
+
+template <int KSTEPS, bool BRACKET, bool PIPE = true>
 static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
+  if (g_k2_pipe < 0) { const char* e = getenv("MFX_K2_PIPE"); g_k2_pipe = (e && e[0] == '0') ? 0 : 1; }
+  if constexpr (PIPE && !BRACKET) { if (!g_k2_pipe) return launch_k2_t<KSTEPS, BRACKET, false>(a, nvox, st); }
   const size_t lds = k2_lds_bytes(KSTEPS, BRACKET, a.T.ldn);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2 kernel needs %zu B of LDS (> 160 KiB): N=%d too large", lds, a.T.N);
-  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET>;
+  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET, PIPE && !BRACKET>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (g_profiling) {
     if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
     HIPCHK(hipEventRecord(g_ev0, st));
   }
-  hipLaunchKernelGGL(kern, dim3(nvox), dim3(MFX_WG), lds, st, a);
+  FitK2Args aa = a;
+  aa.stamps = g_stamps;
+  hipLaunchKernelGGL(kern, dim3(nvox), dim3(MFX_WG), lds, st, aa);
   HIPCHK(hipGetLastError());
   if (g_profiling) {
     HIPCHK(hipEventRecord(g_ev1, st));
