@@ -6,19 +6,29 @@
 //
 // Structure (one 512-thread workgroup = 8 waves, 2 per SIMD, one voxel):
 //   phase 0  y -> LDS; per (direction,row) knot-interval descriptors (binary search) -> LDS
-//   phase 1  column statistics A11,Y1 (dictionary rotated to dir 0) and A22,Y2 (dir 1), one thread
-//            per atom, sequential over the M measurements exactly as mf_utils.py:307-325
+//   phase 1  column statistics ||d||^2 and d.y of both rotated dictionaries, one thread per atom
 //   phase 2  the cross-Gram D1^T D2 on FP64 MFMA (v_mfma_f64_16x16x4_f64): each wave keeps the
 //            A operand (its 16 atoms of D1 over all M rows) in registers, generated straight from
 //            the L2-resident table; D2 is generated 32 atoms at a time into a double-buffered LDS
 //            tile shared by the 8 waves.  The 2x2 NNLS of mf_utils.py:341-379 is evaluated on the
 //            accumulator tile in registers, division-free (candidates are compared as fractions
-//            num/Det by cross-multiplication), keeping one best candidate per (lane,row).
-//   phase 3  candidates within 1e-9*||y||^2 of the best score are re-evaluated in the reference's
-//            exact arithmetic and loop order, the reference's strict-'<' first-hit rule picks the
-//            winner, and the voxel's parameters are written.
+//            by cross-multiplication), keeping one best candidate per (lane,row).
+//   phase 3  short-listed candidates are re-evaluated in the reference's exact arithmetic and loop
+//            order, the reference's strict-'<' first-hit rule picks the winner, and the voxel's
+//            parameters are written.
 // Rotated dictionaries are never materialised in HBM: per voxel the kernel reads y (M doubles),
 // two directions, and writes num_params doubles.
+//
+// Two code paths share phases 0 and 3:
+//   FAST (exact-G protocols): measured on MI355X, FP64 MFMA and VALU instructions do NOT overlap on a
+//        SIMD (the DGEMM MFMA runs on the FP64 vector datapath: SIMD time = 64.4 cycles per MFMA +
+//        ~4.5 cycles per VALU instruction, profiles/r01_micro_mfma_model.txt), so the path minimises
+//        instruction COUNT: both operands are pre-normalised (the accumulator is the cosine c of the
+//        atom pair), the scan handles only the two-positive-weights case (16 VALU per entry); the
+//        single-active cases are represented by the two best single atoms and resolved by phase 3's
+//        family expansion; the next D2 chunk is generated and the previous chunk scanned in slices
+//        inside the MFMA k-loop (hides the L2 latency of the table loads).
+//   GENERIC (protocols with G-bracketed rows, or MFX_K2_PIPE=0): straightforward chunk loop.
 #pragma once
 #include <type_traits>
 
@@ -53,7 +63,7 @@ struct FitK2Args {
 #endif
 
 struct Cand {
-  double score;
+  double score;  // upper bound of the candidate's score
   int i, j;
 };
 
@@ -76,12 +86,10 @@ __device__ __forceinline__ void mfx_static_for(F&& f) {
   }
 }
 
-// PIPE: software-pipelined chunk loop -- the generation of the next D2 chunk and the pair scan of the
-// previous chunk's accumulators are sliced into the MFMA k-loop of the current chunk, so that every
-// wave issues an MFMA every ~130 cycles without VALU-only or load-latency phases.
 template <int KSTEPS, bool BRACKET, bool PIPE>
 __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
-  constexpr int MP = KSTEPS * 4;  // padded measurement count
+  constexpr bool FAST = PIPE && !BRACKET;
+  constexpr int MP = KSTEPS * 4;              // padded measurement count
   constexpr int MPS = ((MP + 15) / 16) * 16;  // rows of one LDS D2 tile (lets the pipelined writer skip a bounds test)
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,20 +101,21 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
 
   // ---- LDS carve-up
-  double* sB = smem;                            // [2 buf][2 tile][MPS][16]
-  double* s_y = sB + 2 * 2 * MPS * 16;          // [MP]
-  double* s_t0 = s_y + MP;                      // [2][MP]
-  double* s_t1 = s_t0 + 2 * MP;                 // [2][MP] (bracket only)
+  double* sB = smem;                             // [2 buf][2 tile][MPS][16]
+  double* s_y = sB + 2 * 2 * MPS * 16;           // [MP]
+  double* s_t0 = s_y + MP;                       // [2][MP]
+  double* s_t1 = s_t0 + 2 * MP;                  // [2][MP] (bracket only)
   double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);  // [MP]
   double* s_dG = s_tG + (BRACKET ? MP : 0);      // [MP]
-  double* s_A11 = s_dG + (BRACKET ? MP : 0);     // [NP]
+  // six [NP] statistic arrays.  GENERIC: A11,Y1,A22,Y2,S2,S1.  FAST: I1=1/|d1|, Z1=d1.y/|d1|, I2, Z2.
+  double* s_A11 = s_dG + (BRACKET ? MP : 0);
   double* s_Y1 = s_A11 + NP;
   double* s_A22 = s_Y1 + NP;
   double* s_Y2 = s_A22 + NP;
-  double* s_S2 = s_Y2 + NP;                     // [NP] single-atom scores of dictionary 2
-  double* s_S1 = s_S2 + NP;                     // [NP] single-atom scores of dictionary 1
-  double* s_red = s_S1 + NP;                    // [16] scratch
-  Cand* s_cand = (Cand*)(s_red + 16);           // [MFX_MAXC]
+  double* s_S2 = s_Y2 + NP;
+  double* s_S1 = s_S2 + NP;
+  double* s_red = s_S1 + NP;                    // [32] scratch
+  Cand* s_cand = (Cand*)(s_red + 32);           // [MFX_MAXC]
   int* s_r0 = (int*)(s_cand + MFX_MAXC);        // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;                    // [2][MP] (bracket only)
   int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);   // [4] counters
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
     }
   }
-  if (tid == 0) { s_cnt[0] = 0; s_red[8] = 0.0; }
+  if (tid == 0) s_cnt[0] = 0;
   __syncthreads();
 
   auto elem = [&](int k, int m, int n) -> double {
@@ -144,22 +153,76 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   };
 
   MFX_STAMP(1);
-  // ---- phase 1: column statistics, reference order (mf_utils.py:307-325), y_sq likewise
+  // ---- phase 1: column statistics (sequential over the measurements, as mf_utils.py:307-325), y_sq likewise
   double y_sq = 0.0;
   for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
+  double my_s[2] = {0.0, 0.0};  // FAST: this thread's best single-atom score per dictionary ...
+  int my_n[2] = {0, 0};         // ... and its (first) atom
   for (int col = tid; col < 2 * NP; col += MFX_WG) {
     const int k = col >= NP, n = col - k * NP;
     double a2 = 0.0, ay = 0.0;
     if (n < N) {
+#pragma unroll 8
       for (int m = 0; m < M; ++m) {
         const double d = elem(k, m, n);
         a2 += d * d;
         ay += s_y[m] * d;
       }
     }
-    (k ? s_A22 : s_A11)[n] = a2;
-    (k ? s_Y2 : s_Y1)[n] = ay;
-    (k ? s_S2 : s_S1)[n] = (n < N && ay > 0.0) ? (ay * ay) / a2 : 0.0;
+    if constexpr (FAST) {
+      const double inv = (n < N && a2 > 0.0) ? 1.0 / sqrt(a2) : 0.0;
+      const double z = ay * inv;
+      (k ? s_A22 : s_A11)[n] = inv;  // I1 / I2
+      (k ? s_Y2 : s_Y1)[n] = z;      // Z1 / Z2
+      const double s = z > 0.0 ? z * z : 0.0;
+      if (s > my_s[k]) { my_s[k] = s; my_n[k] = n; }  // columns are visited in increasing n per thread
+    } else {
+      (k ? s_A22 : s_A11)[n] = a2;
+      (k ? s_Y2 : s_Y1)[n] = ay;
+      (k ? s_S2 : s_S1)[n] = (n < N && ay > 0.0) ? (ay * ay) / a2 : 0.0;
+    }
+  }
+  const double eps_abs = 1e-9 * y_sq;
+  double glb_run = 0.0;  // running best lower bound on the score (same value in every thread)
+  if constexpr (FAST) {
+    // best single atom of each dictionary (first index on ties): they stand for every pair whose
+    // optimum has one active atom (mf_utils.py:357-379); phase 3 expands the winner's family exactly
+    double* s_bs = s_red;            // [2][8] per-wave bests
+    int* s_bn = (int*)(s_red + 16);  // [2][8]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double s = my_s[k];
+      int n = my_n[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double s2 = __shfl_xor(s, o);
+        const int n2 = __shfl_xor(n, o);
+        const bool take = (s2 > s) || (s2 == s && n2 < n);
+        s = take ? s2 : s;
+        n = take ? n2 : n;
+      }
+      if (lane == 0) { s_bs[k * 8 + wave] = s; s_bn[k * 8 + wave] = n; }
+    }
+    __syncthreads();
+    double best1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double s = s_bs[k * 8];
+      int n = s_bn[k * 8];
+      for (int w = 1; w < 8; ++w) {
+        const double s2 = s_bs[k * 8 + w];
+        const int n2 = s_bn[k * 8 + w];
+        if (s2 > s || (s2 == s && n2 < n)) { s = s2; n = n2; }
+      }
+      best1 = fmax(best1, s);
+      if (tid == 0 && s > 0.0) {
+        const int slot = s_cnt[0]++;
+        s_cand[slot].score = s + eps_abs;
+        s_cand[slot].i = k ? 0 : n;
+        s_cand[slot].j = k ? n : 0;
+      }
+    }
+    glb_run = best1;
   }
   __syncthreads();
 
@@ -169,8 +232,9 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     const int n = ch * 32 + c;
     double* dst = sB + (size_t)buf * (2 * MPS * 16) + (c >> 4) * (MPS * 16) + (c & 15);
     if (n < NP) {
+      const double sc = FAST ? s_A22[n] : 1.0;  // FAST: normalised columns
 #pragma unroll 4
-      for (int m = m0; m < MP; m += 16) dst[m * 16] = elem(1, m, n);
+      for (int m = m0; m < MP; m += 16) dst[m * 16] = FAST ? elem(1, m, n) * sc : elem(1, m, n);
     } else {
       for (int m = m0; m < MP; m += 16) dst[m * 16] = 0.0;
     }
@@ -179,28 +243,19 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   MFX_STAMP(2);
   const int nchunks = (ntiles + 1) >> 1;
   const int nrounds = (ntiles + 7) >> 3;
-  const double eps_abs = 1e-9 * y_sq;
-  double glb_run = 0.0;  // running best lower bound on the score (same value in every thread)
 
   for (int round = 0; round < nrounds; ++round) {
     const int rt = round * 8 + wave;
     const bool rt_valid = rt < ntiles;  // wave-uniform
+    const int rtc = rt_valid ? rt : 0;
     // A operand: this wave's 16 atoms of D1, all KSTEPS k-steps, in registers
     double afr[KSTEPS];
+    {
+      const double sc = FAST ? s_A11[rtc * 16 + lc] : 1.0;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rt * 16 + lc) : 0.0;
-    // per-lane row statistics (rows lg + 4r of the tile)
-    constexpr bool ROWS_IN_LDS = PIPE && !BRACKET;  // pipelined path re-reads them from LDS (saves 24 VGPRs)
-    double A11r[ROWS_IN_LDS ? 1 : 4], Y1r[ROWS_IN_LDS ? 1 : 4], s1r[ROWS_IN_LDS ? 1 : 4];
-    bool rowok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = (rt_valid ? rt : 0) * 16 + lg + 4 * r;
-      rowok[r] = rt_valid && (i < N);
-      if constexpr (!ROWS_IN_LDS) {
-        A11r[r] = s_A11[i];
-        Y1r[r] = s_Y1[i];
-        s1r[r] = s_S1[i];
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const double v = rt_valid ? elem(0, 4 * kk + lg, rtc * 16 + lc) : 0.0;
+        afr[kk] = FAST ? v * sc : v;
       }
     }
     double bp[4], bq[4];
@@ -208,115 +263,137 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bp[r] = 0.0; bq[r] = 1.0; bj[r] = -1; }
 
-    // pair scan of one accumulator entry (row r of the lane, column j)
-    auto scan_one = [&](double A12, int r, int j, bool colok, double A22, double Y2, double s2) {
-      double A11v, Y1v, s1v;
-      if constexpr (ROWS_IN_LDS) {
-        const int i = (rt_valid ? rt : 0) * 16 + lg + 4 * r;
-        A11v = s_A11[i]; Y1v = s_Y1[i]; s1v = s_S1[i];
-      } else {
-        A11v = A11r[r]; Y1v = Y1r[r]; s1v = s1r[r];
-      }
-      const double d1 = fma(-A12, Y2, A22 * Y1v);
-      const double d2 = fma(-A12, Y1v, A11v * Y2);
-      const double pd = A11v * A22;
-      const double Det = fma(-A12, A12, pd);
-      const double num = fma(Y2, d2, Y1v * d1);
-      // (numerically) collinear atom pairs carry no two-atom information: rank them by their
-      // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
-      const bool both = (d1 > 0.0) & (d2 > 0.0) & (Det > MFX_DET_REL * pd);  // bitwise: no short-circuit branches
-      const double smax = fmax(s1v, s2);
-      double p = both ? num : smax;
-      const double q = both ? Det : 1.0;
-      p = (colok & rowok[r]) ? p : 0.0;
-      const bool better = p * bq[r] > bp[r] * q;
-      bp[r] = better ? p : bp[r];
-      bq[r] = better ? q : bq[r];
-      bj[r] = better ? j : bj[r];
-    };
-
     if (round == 0) MFX_STAMP(3);
     gen_chunk(0, 0);
     __syncthreads();
     if (round == 0) MFX_STAMP(4);
-    if constexpr (PIPE && !BRACKET) {
-      constexpr int NEL = (MP + 15) / 16;                              // D2 elements per thread per chunk
+
+    if constexpr (FAST) {
+      double z1r[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
+      // two-positive-weights case of one accumulator entry: c = cos(atom i, atom j), z = d.y/|d|
+      auto scan_one = [&](double c, int r, int j, double z2) {
+        const double e1 = fma(-c, z2, z1r[r]);
+        const double e2 = fma(-c, z1r[r], z2);
+        const double den = fma(-c, c, 1.0);
+        const double num = fma(z2, e2, z1r[r] * e1);
+        const bool better = (e1 > 0.0) & (e2 > 0.0) & (den > MFX_DET_REL) & (num * bq[r] > bp[r] * den);
+        bp[r] = better ? num : bp[r];
+        bq[r] = better ? den : bq[r];
+        bj[r] = better ? j : bj[r];
+      };
+      constexpr int NEL = (MP + 15) / 16;                                  // D2 elements per thread per chunk
       constexpr int GS = (KSTEPS - 5) / NEL > 0 ? (KSTEPS - 5) / NEL : 1;  // k-steps between two element loads
-      constexpr int GD = 4;                                            // load -> use distance in k-steps
-      constexpr int SU = (KSTEPS - 2) / 8 > 0 ? (KSTEPS - 2) / 8 : 1;  // k-steps between two scan units
+      constexpr int GD = 4;                                                // load -> use distance in k-steps
+      constexpr int SU = (KSTEPS - 2) / 8 > 0 ? (KSTEPS - 2) / 8 : 1;      // k-steps between two scan units
+      constexpr int PD = 3;                                                // B operand read-ahead in k-steps
       static_assert(GS * (NEL - 1) + GD < KSTEPS, "generation slices do not fit in the k-loop");
       static_assert(SU * 7 + 2 < KSTEPS, "scan slices do not fit in the k-loop");
       const int gc = tid & 31, gm0 = tid >> 5;
-      const int* gr = s_r0 + MP;       // direction-1 descriptors
+      const int* gr = s_r0 + MP;  // direction-1 descriptors
       const double* gt = s_t0 + MP;
       d4 accP0 = {0, 0, 0, 0}, accP1 = {0, 0, 0, 0};
+      int jprev = 0;      // column (tile 0, this lane) of the accumulators waiting to be scanned
+      bool pend = false;  // wave-uniform
       for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
-        const int n_next = min((ch + 1) * 32 + gc, NP - 1);
+        const int n_next = (ch + 1) * 32 + gc;
+        const double gsc = (n_next < NP) ? s_A22[n_next] : 0.0;  // 0 -> columns beyond the dictionary stay zero
         double* gdst = sB + (size_t)(buf ^ 1) * (2 * MPS * 16) + (gc >> 4) * (MPS * 16) + (gc & 15);
-        const double2* gsrc = tab + n_next;
+        const double2* gsrc = tab + min(n_next, NP - 1);
         const double* b0p = sB + (size_t)buf * (2 * MPS * 16) + lg * 16 + lc;
         const double* b1p = b0p + MPS * 16;
-        // column statistics of the PREVIOUS chunk (scanned during this chunk's MFMAs)
-        const int jp0 = (ch - 1) * 32 + lc, jp1 = jp0 + 16;
-        const bool okp0 = ch > 0 && jp0 < N, okp1 = ch > 0 && jp1 < N;
-        const int jq0 = okp0 ? jp0 : 0, jq1 = okp1 ? jp1 : 0;
-        const double A22p0 = s_A22[jq0], Y2p0 = s_Y2[jq0], S2p0 = s_S2[jq0];
-        const double A22p1 = s_A22[jq1], Y2p1 = s_Y2[jq1], S2p1 = s_S2[jq1];
+        // statistics of the columns whose accumulators are pending
+        const double z2p0 = (pend && jprev < NP) ? s_Y2[min(jprev, NP - 1)] : 0.0;
+        const double z2p1 = (pend && jprev + 16 < NP) ? s_Y2[min(jprev + 16, NP - 1)] : 0.0;
+        const bool mma = rt_valid;  // wave-uniform
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double2 gl[3];
         double gtv[3];
-        // B operands are read from LDS PD k-steps ahead of the MFMA that consumes them (the LDS latency
-        // is longer than the ~130-cycle MFMA issue interval of one wave)
-        constexpr int PD = 3;
-        double bb0[PD + 1], bb1[PD + 1];
+        auto body = [&](auto mma_c) {
+          constexpr bool MMA = decltype(mma_c)::value;
+          double bb0[PD + 1], bb1[PD + 1];
+          if constexpr (MMA) {
 #pragma unroll
-        for (int q = 0; q < PD; ++q) { bb0[q] = b0p[q * 64]; bb1[q] = b1p[q * 64]; }
-        mfx_static_for<0, KSTEPS>([&](auto kc) {
-          constexpr int kk = decltype(kc)::value;
-          // (the whole body is branch-free: idle waves of the ragged last round multiply zeros, the
-          // last chunk generates a clamped dummy successor, rows beyond MP land in the tile's padding)
-          {
-            if constexpr (kk + PD < KSTEPS) {
-              bb0[(kk + PD) % (PD + 1)] = b0p[(kk + PD) * 64];
-              bb1[(kk + PD) % (PD + 1)] = b1p[(kk + PD) * 64];
+            for (int q = 0; q < PD; ++q) { bb0[q] = b0p[q * 64]; bb1[q] = b1p[q * 64]; }
+          }
+          mfx_static_for<0, KSTEPS>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
+            if constexpr (MMA) {
+              if constexpr (kk + PD < KSTEPS) {
+                bb0[(kk + PD) % (PD + 1)] = b0p[(kk + PD) * 64];
+                bb1[(kk + PD) % (PD + 1)] = b1p[(kk + PD) * 64];
+              }
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb0[kk % (PD + 1)], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb1[kk % (PD + 1)], acc1, 0, 0, 0);
             }
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb0[kk % (PD + 1)], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb1[kk % (PD + 1)], acc1, 0, 0, 0);
-          }
-          // slice of the next chunk's generation: issue the load of element p ...
-          if constexpr (kk % GS == 0 && kk / GS < NEL) {
-            constexpr int p = kk / GS;
-            const int m = min(gm0 + 16 * p, MP - 1);
-            gtv[p % 3] = gt[m];
-            gl[p % 3] = gsrc[(size_t)gr[m] * ldn];
-          }
-          // ... and GD k-steps later turn it into a D2 entry in the other LDS buffer
-          if constexpr (kk >= GD && (kk - GD) % GS == 0 && (kk - GD) / GS < NEL) {
-            constexpr int p = (kk - GD) / GS;
-            gdst[(gm0 + 16 * p) * 16] = gl[p % 3].y * gtv[p % 3] + gl[p % 3].x;
-          }
-          // slice of the previous chunk's pair scan (chunk -1 does not exist: okp* are false then)
-          if constexpr (kk >= 2 && (kk - 2) % SU == 0 && (kk - 2) / SU < 8) {
-            constexpr int u = (kk - 2) / SU;
-            if constexpr (u < 4) scan_one(accP0[u & 3], u & 3, jp0, okp0, A22p0, Y2p0, S2p0);
-            else scan_one(accP1[u & 3], u & 3, jp1, okp1, A22p1, Y2p1, S2p1);
-          }
-        });
+            // slice of the next chunk's generation: issue the load of element p ...
+            if constexpr (kk % GS == 0 && kk / GS < NEL) {
+              constexpr int p = kk / GS;
+              const int m = min(gm0 + 16 * p, MP - 1);
+              gtv[p % 3] = gt[m];
+              gl[p % 3] = gsrc[(size_t)gr[m] * ldn];
+            }
+            // ... and GD k-steps later turn it into a (normalised) D2 entry in the other LDS buffer;
+            // rows beyond MP land in the tile's padding, the last chunk writes a dummy successor
+            if constexpr (kk >= GD && (kk - GD) % GS == 0 && (kk - GD) / GS < NEL) {
+              constexpr int p = (kk - GD) / GS;
+              gdst[(gm0 + 16 * p) * 16] = fma(gl[p % 3].y, gtv[p % 3], gl[p % 3].x) * gsc;
+            }
+            // slice of the pending pair scan (z2p* are 0 when nothing is pending: no candidate can form)
+            if constexpr (kk >= 2 && (kk - 2) % SU == 0 && (kk - 2) / SU < 8) {
+              constexpr int u = (kk - 2) / SU;
+              if constexpr (u < 4) scan_one(accP0[u & 3], u & 3, jprev, z2p0);
+              else scan_one(accP1[u & 3], u & 3, jprev + 16, z2p1);
+            }
+          });
+        };
+        if (mma) body(std::true_type{}); else body(std::false_type{});
         accP0 = acc0;
         accP1 = acc1;
+        pend = mma;
+        jprev = ch * 32 + lc;
         __syncthreads();
       }
-      {  // scan of the last chunk
-        const int j0 = (nchunks - 1) * 32 + lc, j1 = j0 + 16;
-        const bool ok0 = j0 < N, ok1 = j1 < N;
-        const int q0 = ok0 ? j0 : 0, q1 = ok1 ? j1 : 0;
+      if (pend) {  // scan of the last computed chunk
+        const double z20 = (jprev < NP) ? s_Y2[min(jprev, NP - 1)] : 0.0;
+        const double z21 = (jprev + 16 < NP) ? s_Y2[min(jprev + 16, NP - 1)] : 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scan_one(accP0[r], r, j0, ok0, s_A22[q0], s_Y2[q0], s_S2[q0]);
+        for (int r = 0; r < 4; ++r) scan_one(accP0[r], r, jprev, z20);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) scan_one(accP1[r], r, j1, ok1, s_A22[q1], s_Y2[q1], s_S2[q1]);
+        for (int r = 0; r < 4; ++r) scan_one(accP1[r], r, jprev + 16, z21);
       }
     } else {
+      double A11r[4], Y1r[4], s1r[4];
+      bool rowok[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = rtc * 16 + lg + 4 * r;
+        rowok[r] = rt_valid && (i < N);
+        A11r[r] = s_A11[i];
+        Y1r[r] = s_Y1[i];
+        s1r[r] = s_S1[i];
+      }
+      // pair scan of one accumulator entry (row r of the lane, column j), all cases of mf_utils.py:348-379
+      auto scan_one = [&](double A12, int r, int j, bool colok, double A22, double Y2, double s2) {
+        const double d1 = fma(-A12, Y2, A22 * Y1r[r]);
+        const double d2 = fma(-A12, Y1r[r], A11r[r] * Y2);
+        const double pd = A11r[r] * A22;
+        const double Det = fma(-A12, A12, pd);
+        const double num = fma(Y2, d2, Y1r[r] * d1);
+        // (numerically) collinear atom pairs carry no two-atom information: rank them by their
+        // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
+        const bool both = (d1 > 0.0) & (d2 > 0.0) & (Det > MFX_DET_REL * pd);
+        const double smax = fmax(s1r[r], s2);
+        double p = both ? num : smax;
+        const double q = both ? Det : 1.0;
+        p = (colok & rowok[r]) ? p : 0.0;
+        const bool better = p * bq[r] > bp[r] * q;
+        bp[r] = better ? p : bp[r];
+        bq[r] = better ? q : bq[r];
+        bj[r] = better ? j : bj[r];
+      };
       for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
@@ -355,10 +432,15 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     for (int r = 0; r < 4; ++r) {
       sc[r] = -1.0;
       er[r] = 0.0;
-      if (bj[r] >= 0) {
+      const int i = rtc * 16 + lg + 4 * r;
+      if (bj[r] >= 0 && rt_valid && i < N) {
         sc[r] = bp[r] / bq[r];
-        const double pd = s_A11[(rt_valid ? rt : 0) * 16 + lg + 4 * r] * s_A22[bj[r]];
-        er[r] = (bq[r] == 1.0) ? 0.0 : sc[r] * (MFX_A12_REL * pd / bq[r]);
+        if constexpr (FAST) {
+          er[r] = sc[r] * (MFX_A12_REL / bq[r]);  // bq = 1 - c^2
+        } else {
+          const double pd = s_A11[i] * s_A22[bj[r]];
+          er[r] = (bq[r] == 1.0) ? 0.0 : sc[r] * (MFX_A12_REL * pd / bq[r]);
+        }
         llb = fmax(llb, sc[r] - er[r]);
       }
     }
@@ -371,11 +453,11 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     glb_run = fmax(glb_run, rlb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (bj[r] >= 0 && sc[r] > 0.0 && sc[r] + er[r] + eps_abs >= glb_run) {
+      if (sc[r] > 0.0 && sc[r] + er[r] + eps_abs >= glb_run) {
         const int slot = atomicAdd(&s_cnt[0], 1);
         if (slot < MFX_MAXC) {
-          s_cand[slot].score = sc[r] + er[r] + eps_abs;   // upper bound
-          s_cand[slot].i = rt * 16 + lg + 4 * r;
+          s_cand[slot].score = sc[r] + er[r] + eps_abs;  // upper bound
+          s_cand[slot].i = rtc * 16 + lg + 4 * r;
           s_cand[slot].j = bj[r];
         }
       }
@@ -390,6 +472,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   // the case analysis of mf_utils.py:341-379
   auto exact_pair = [&](int i, int j, double& w0, double& w1, double& res) {
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll 4
     for (int m = 0; m < M; ++m) {
       const double d1 = elem(0, m, i), d2 = elem(1, m, j), ym = s_y[m];
       a11 += d1 * d1;
@@ -401,10 +484,10 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     nnls2_exact(y_sq, a11, a12, a22, y1, y2, w0, w1, res);
   };
   // lexicographic (res, idx) minimum over the workgroup; idx = i*N + j is the reference's scan order
-  double* s_rres = (double*)sB;               // [8] per-wave partials (B buffers are idle now)
-  long* s_ridx = (long*)(s_rres + 8);         // [8]
-  double* s_rw = (double*)(s_ridx + 8);       // [8][2]
-  double* s_win = s_rw + 16;                  // winner: res, w0, w1, (long) idx
+  double* s_rres = (double*)sB;          // [8] per-wave partials (B buffers are idle now)
+  long* s_ridx = (long*)(s_rres + 8);    // [8]
+  double* s_rw = (double*)(s_ridx + 8);  // [8][2]
+  double* s_win = s_rw + 16;             // winner: res, w0, w1, (long) idx
   auto block_argmin = [&](double res, long idx, double w0, double w1) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -423,7 +506,8 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       for (int w = 0; w < 8; ++w) {
         const double r = s_rres[w];
         const long ix = s_ridx[w];
-        if (r < br || (r == br && bi >= 0 && ix >= 0 && ix < bi)) { br = r; bi = ix; b0 = s_rw[2 * w]; b1 = s_rw[2 * w + 1]; }
+        if (ix < 0) continue;
+        if (r < br || (r == br && bi >= 0 && ix < bi)) { br = r; bi = ix; b0 = s_rw[2 * w]; b1 = s_rw[2 * w + 1]; }
       }
       s_win[0] = br; s_win[1] = b0; s_win[2] = b1; ((long*)s_win)[3] = bi;
     }
@@ -445,9 +529,9 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     block_argmin(res, idx, w0, w1);
   }
   // Near-zero second weight: every pair sharing the active atom fits equally well up to rounding
-  // (e.g. a single-fascicle signal fitted with two fascicles).  The reference then returns the first
-  // pair of that row/column attaining the minimum of its own rounded residual: evaluate the whole
-  // family exactly.  Wave-uniform branch on the broadcast winner.
+  // (a single-fascicle signal fitted with two fascicles, or any voxel whose optimum has one active atom).
+  // The reference then returns the first pair of that row/column attaining the minimum of its own
+  // rounded residual: evaluate the whole family exactly.  Wave-uniform branch on the broadcast winner.
   for (int pass = 0; pass < 2; ++pass) {
     const double bw0 = s_win[1], bw1 = s_win[2];
     const long bidx = ((long*)s_win)[3];

@@ -232,7 +232,7 @@ extern "C" void mfx_plan_destroy(mfx_plan* p) {
 static size_t k2_lds_bytes(int ksteps, bool bracket, int NP) {
   const size_t MP = (size_t)ksteps * 4;
   const size_t MPS = (MP + 15) / 16 * 16;
-  size_t dbl = 2 * 2 * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 16;
+  size_t dbl = 2 * 2 * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 32;
   size_t bytes = dbl * 8 + sizeof(Cand) * MFX_MAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
   return bytes;
 }
