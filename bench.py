@@ -166,7 +166,7 @@ def main():
                     traffic = None
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "mfx_fit_k2_kernel<50,false>", "kernel_ms": round(kavg, 3),
+                    "kernel": "mfx_fit_k2_kernel<50,false,true,8,2,2>", "kernel_ms": round(kavg, 3),
                     "flop_per_voxel": FLOP_PER_VOXEL, "hbm_bytes_per_voxel_algorithmic": BYTES_PER_VOXEL,
                     "achieved_hbm_GBps_algorithmic": round(BYTES_PER_VOXEL * V / (kavg * 1e-3) / 1e9, 3)}
         cpu = None

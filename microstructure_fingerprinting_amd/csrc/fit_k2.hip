@@ -86,9 +86,16 @@ __device__ __forceinline__ void mfx_static_for(F&& f) {
   }
 }
 
-template <int KSTEPS, bool BRACKET, bool PIPE>
-__global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
+// NW waves per workgroup, TILES 16-atom column tiles per D2 chunk, NBUF LDS buffers for the chunks.
+// (8, 2, 2) is the tuned configuration (M <= 200: the A operand fits in 100 VGPRs, 2 waves per SIMD);
+// (4, 1, 1) serves long protocols (M up to 560): one wave per SIMD owns the whole 512-register file.
+template <int KSTEPS, bool BRACKET, bool PIPE, int NW = 8, int TILES = 2, int NBUF = 2>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(FitK2Args a) {
   constexpr bool FAST = PIPE && !BRACKET;
+  constexpr int WG = NW * 64;
+  static_assert(!FAST || (NW == 8 && TILES == 2 && NBUF == 2), "the pipelined path is written for 8 waves, 2 tiles, 2 buffers");
+  static_assert(TILES == 1 || TILES == 2, "TILES");
+  static_assert(NBUF == 1 || NBUF == 2, "NBUF");
   constexpr int MP = KSTEPS * 4;              // padded measurement count
   constexpr int MPS = ((MP + 15) / 16) * 16;  // rows of one LDS D2 tile (lets the pipelined writer skip a bounds test)
   extern __shared__ double smem[];
@@ -101,8 +108,8 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
 
   // ---- LDS carve-up
-  double* sB = smem;                             // [2 buf][2 tile][MPS][16]
-  double* s_y = sB + 2 * 2 * MPS * 16;           // [MP]
+  double* sB = smem;                             // [NBUF][TILES][MPS][16]
+  double* s_y = sB + NBUF * TILES * MPS * 16;    // [MP]
   double* s_t0 = s_y + MP;                       // [2][MP]
   double* s_t1 = s_t0 + 2 * MP;                  // [2][MP] (bracket only)
   double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);  // [MP]
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   // ---- phase 0: y, descriptors
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
-  for (int m = tid; m < MP; m += MFX_WG) s_y[m] = (m < M) ? yv[m] : 0.0;
-  for (int idx = tid; idx < 2 * MP; idx += MFX_WG) {
+  for (int m = tid; m < MP; m += WG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int idx = tid; idx < 2 * MP; idx += WG) {
     const int k = idx / MP, m = idx - k * MP;
     RowDesc rd;
     rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;  // padded rows -> the all-zero table row
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
   double my_s[2] = {0.0, 0.0};  // FAST: this thread's best single-atom score per dictionary ...
   int my_n[2] = {0, 0};         // ... and its (first) atom
-  for (int col = tid; col < 2 * NP; col += MFX_WG) {
+  for (int col = tid; col < 2 * NP; col += WG) {
     const int k = col >= NP, n = col - k * NP;
     double a2 = 0.0, ay = 0.0;
     if (n < N) {
@@ -226,26 +233,28 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
   }
   __syncthreads();
 
-  // generation of one 32-atom chunk of D2 into LDS buffer `buf`: thread -> (atom c, rows m0+16p)
+  // generation of one (16*TILES)-atom chunk of D2 into LDS buffer `buf`: thread -> (atom c, rows m0 + RS*p)
+  constexpr int CW = 16 * TILES;  // atoms per chunk
+  constexpr int RS = WG / CW;     // row stride of one thread
   auto gen_chunk = [&](int ch, int buf) {
-    const int c = tid & 31, m0 = tid >> 5;
-    const int n = ch * 32 + c;
-    double* dst = sB + (size_t)buf * (2 * MPS * 16) + (c >> 4) * (MPS * 16) + (c & 15);
+    const int c = tid % CW, m0 = tid / CW;
+    const int n = ch * CW + c;
+    double* dst = sB + (size_t)buf * (TILES * MPS * 16) + (c >> 4) * (MPS * 16) + (c & 15);
     if (n < NP) {
       const double sc = FAST ? s_A22[n] : 1.0;  // FAST: normalised columns
 #pragma unroll 4
-      for (int m = m0; m < MP; m += 16) dst[m * 16] = FAST ? elem(1, m, n) * sc : elem(1, m, n);
+      for (int m = m0; m < MP; m += RS) dst[m * 16] = FAST ? elem(1, m, n) * sc : elem(1, m, n);
     } else {
-      for (int m = m0; m < MP; m += 16) dst[m * 16] = 0.0;
+      for (int m = m0; m < MP; m += RS) dst[m * 16] = 0.0;
     }
   };
 
   MFX_STAMP(2);
-  const int nchunks = (ntiles + 1) >> 1;
-  const int nrounds = (ntiles + 7) >> 3;
+  const int nchunks = (ntiles + TILES - 1) / TILES;
+  const int nrounds = (ntiles + NW - 1) / NW;
 
   for (int round = 0; round < nrounds; ++round) {
-    const int rt = round * 8 + wave;
+    const int rt = round * NW + wave;
     const bool rt_valid = rt < ntiles;  // wave-uniform
     const int rtc = rt_valid ? rt : 0;
     // A operand: this wave's 16 atoms of D1, all KSTEPS k-steps, in registers
@@ -395,23 +404,30 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
         bj[r] = better ? j : bj[r];
       };
       for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
+        const int buf = (NBUF == 2) ? (ch & 1) : 0;
+        if constexpr (NBUF == 2) {
+          if (ch + 1 < nchunks) gen_chunk(ch + 1, buf ^ 1);
+        } else if (ch > 0) {
+          gen_chunk(ch, 0);   // single buffer: generate, barrier, consume, barrier
+          __syncthreads();
+        }
         if (rt_valid) {
-          const double* b0p = sB + (size_t)buf * (2 * MPS * 16) + lg * 16 + lc;
-          const double* b1p = b0p + MPS * 16;
+          const double* b0p = sB + (size_t)buf * (TILES * MPS * 16) + lg * 16 + lc;
+          const double* b1p = b0p + (TILES == 2 ? MPS * 16 : 0);
           d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
           for (int kk = 0; kk < KSTEPS; ++kk) {
             const double b0 = b0p[kk * 64];
-            const double b1 = b1p[kk * 64];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b1, acc1, 0, 0, 0);
+            if constexpr (TILES == 2) {
+              const double b1 = b1p[kk * 64];
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], b1, acc1, 0, 0, 0);
+            }
           }
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
+          for (int t = 0; t < TILES; ++t) {
             const d4 acc = t ? acc1 : acc0;
-            const int j = ch * 32 + t * 16 + lc;
+            const int j = ch * CW + t * 16 + lc;
             const bool colok = j < N;
             const int jq = colok ? j : 0;
             const double A22 = s_A22[jq], Y2 = s_Y2[jq], s2 = s_S2[jq];
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     __syncthreads();
     double rlb = s_red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) rlb = fmax(rlb, s_red[w]);
+    for (int w = 1; w < NW; ++w) rlb = fmax(rlb, s_red[w]);
     glb_run = fmax(glb_run, rlb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -503,7 +519,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
       // fold into the current winner (strict '<' on res, ties -> earlier pair in scan order)
       double br = s_win[0], b0 = s_win[1], b1 = s_win[2];
       long bi = ((long*)s_win)[3];
-      for (int w = 0; w < 8; ++w) {
+      for (int w = 0; w < NW; ++w) {
         const double r = s_rres[w];
         const long ix = s_ridx[w];
         if (ix < 0) continue;
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(MFX_WG, 2) void mfx_fit_k2_kernel(FitK2Args a) {
     if (!row_family && !col_family) continue;
     double res = INFINITY, w0 = 0.0, w1 = 0.0;
     long idx = -1;
-    for (int n = tid; n < N; n += MFX_WG) {
+    for (int n = tid; n < N; n += WG) {
       double r, u0, u1;
       const int i = row_family ? bi : n, j = row_family ? n : bj2;
       exact_pair(i, j, u0, u1, r);

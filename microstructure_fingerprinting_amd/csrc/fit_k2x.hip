@@ -38,9 +38,12 @@ struct CandX {
   int i, j, e, pad;
 };
 
-template <int KSTEPS, bool BRACKET>
-__global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
+// NW waves per workgroup and NBUF LDS chunk buffers: (8, 2) for M <= 200, (4, 1) for long protocols
+// (one wave per SIMD owns the 512-register file; see fit_k2.hip).
+template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   constexpr int MP = KSTEPS * 4;
+  constexpr int WG = NW * 64;
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   const int vox = a.vox_list ? a.vox_list[a.vox_base + blockIdx.x] : a.vox_base + blockIdx.x;
   double* __restrict__ wsA = a.ws + (size_t)blockIdx.x * 2 * NP * MFX_XS;  // [k][n][e]
 
-  double* sB = smem;                              // [2 buf][MP][16]
-  double* s_y = sB + 2 * MP * 16;                 // [MP]
+  double* sB = smem;                              // [NBUF][MP][16]
+  double* s_y = sB + NBUF * MP * 16;              // [MP]
   double* s_t0 = s_y + MP;                        // [2][MP]
   double* s_t1 = s_t0 + 2 * MP;                   // [2][MP] (bracket)
   double* s_tG = s_t1 + (BRACKET ? 2 * MP : 0);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   double* s_A22 = s_Y1 + NP;
   double* s_Y2 = s_A22 + NP;
   double* s_a1x = s_Y2 + NP;                      // [8 waves][16 rows][XS]
-  double* s_a2x = s_a1x + 8 * 16 * MFX_XS;        // [2 buf][16 cols][XS]
+  double* s_a2x = s_a1x + NW * 16 * MFX_XS;       // [2 buf][16 cols][XS]
   double* s_Yx = s_a2x + 2 * 16 * MFX_XS;         // [XS]
   double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
   double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
   const double* __restrict__ xx = a.X.x;
-  for (int m = tid; m < MP; m += MFX_XWG) s_y[m] = (m < M) ? yv[m] : 0.0;
-  for (int idx = tid; idx < 2 * MP; idx += MFX_XWG) {
+  for (int m = tid; m < MP; m += WG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int idx = tid; idx < 2 * MP; idx += WG) {
     const int k = idx / MP, m = idx - k * MP;
     RowDesc rd;
     rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
       if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
     }
   }
-  for (int q = tid; q < MFX_XS * MFX_XS; q += MFX_XWG) {
+  for (int q = tid; q < MFX_XS * MFX_XS; q += WG) {
     const int p = q / MFX_XS, r = q - p * MFX_XS;
     s_Gxx[q] = (p < NX && r < NX) ? a.X.Gxx[p * NX + r] : 0.0;
   }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   // ---- phase 1: column statistics + inner products with the extra columns (sequential over rows)
   double y_sq_seq = 0.0;
   for (int m = 0; m < M; ++m) y_sq_seq += s_y[m] * s_y[m];
-  for (int col = tid; col < 2 * NP; col += MFX_XWG) {
+  for (int col = tid; col < 2 * NP; col += WG) {
     const int k = col >= NP, n = col - k * NP;
     double a2 = 0.0, ay = 0.0, ax[MFX_XS];
 #pragma unroll
@@ -141,22 +144,22 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   const double y_sq = (Kp == 4) ? s_red[16] : y_sq_seq;
 
   auto gen_chunk = [&](int ch, int buf) {
-    const int c = tid & 15, m0 = tid >> 4;  // 32 row groups
+    const int c = tid & 15, m0 = tid >> 4;  // WG/16 row groups
     const int n = ch * 16 + c;
     double* dst = sB + (size_t)buf * (MP * 16) + c;
-    for (int m = m0; m < MP; m += 32) dst[m * 16] = elem(1, m, n);
+    for (int m = m0; m < MP; m += WG / 16) dst[m * 16] = elem(1, m, n);
     if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms
       const int cc = tid / MFX_XS, e = tid - cc * MFX_XS;
       s_a2x[(buf * 16 + cc) * MFX_XS + e] = wsA[((size_t)NP + ch * 16 + cc) * MFX_XS + e];
     }
   };
 
-  const int nrounds = (ntiles + 7) >> 3;
+  const int nrounds = (ntiles + NW - 1) / NW;
   const double eps_abs = 1e-9 * y_sq;
   double gmax_run = 0.0;
 
   for (int round = 0; round < nrounds; ++round) {
-    const int rt = round * 8 + wave;
+    const int rt = round * NW + wave;
     const bool rt_valid = rt < ntiles;
     double afr[KSTEPS];
 #pragma unroll
@@ -172,8 +175,13 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
     gen_chunk(0, 0);
     __syncthreads();
     for (int ch = 0; ch < ntiles; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+      const int buf = (NBUF == 2) ? (ch & 1) : 0;
+      if constexpr (NBUF == 2) {
+        if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+      } else if (ch > 0) {
+        gen_chunk(ch, 0);
+        __syncthreads();
+      }
       if (rt_valid) {
         const double* bp = sB + (size_t)buf * (MP * 16) + lg * 16 + lc;
         d4x acc = {0, 0, 0, 0};
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
     __syncthreads();
     double rmax = s_red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) rmax = fmax(rmax, s_red[w]);
+    for (int w = 1; w < NW; ++w) rmax = fmax(rmax, s_red[w]);
     gmax_run = fmax(gmax_run, rmax);
     const double thr = gmax_run - eps_abs;
 #pragma unroll
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(MFX_XWG, 2) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   const double thr_final = gmax_run - eps_abs;
   __syncthreads();
   // scratch inside the (now idle) B buffers: 6*XMAXC + 8 + MP doubles must fit in 2*MP*16
-  static_assert(2 * MP * 16 >= 6 * MFX_XMAXC + 8 + MP, "B buffers too small for the exact-stage scratch");
+  static_assert(NBUF * MP * 16 >= 6 * MFX_XMAXC + 8 + MP, "B buffers too small for the exact-stage scratch");
   double* s_rres = (double*)sB;                  // [XMAXC]
   long* s_rkey = (long*)(s_rres + MFX_XMAXC);    // [XMAXC]
   double* s_rw = (double*)(s_rkey + MFX_XMAXC);  // [XMAXC][4]

@@ -229,10 +229,10 @@ extern "C" void mfx_plan_destroy(mfx_plan* p) {
 
 // ---------------------------------------------------------------------------------------------
 // kernel dispatch
-static size_t k2_lds_bytes(int ksteps, bool bracket, int NP) {
+static size_t k2_lds_bytes(int ksteps, bool bracket, int NP, int tiles, int nbuf) {
   const size_t MP = (size_t)ksteps * 4;
   const size_t MPS = (MP + 15) / 16 * 16;
-  size_t dbl = 2 * 2 * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 32;
+  size_t dbl = (size_t)nbuf * tiles * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 32;
   size_t bytes = dbl * 8 + sizeof(Cand) * MFX_MAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
   return bytes;
 }
@@ -241,13 +241,13 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
 
-template <int KSTEPS, bool BRACKET, bool PIPE = true>
+template <int KSTEPS, bool BRACKET, bool PIPE = true, int NW = 8, int TILES = 2, int NBUF = 2>
 static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
   if (g_k2_pipe < 0) { const char* e = getenv("MFX_K2_PIPE"); g_k2_pipe = (e && e[0] == '0') ? 0 : 1; }
-  if constexpr (PIPE && !BRACKET) { if (!g_k2_pipe) return launch_k2_t<KSTEPS, BRACKET, false>(a, nvox, st); }
-  const size_t lds = k2_lds_bytes(KSTEPS, BRACKET, a.T.ldn);
+  if constexpr (PIPE && !BRACKET) { if (!g_k2_pipe) return launch_k2_t<KSTEPS, BRACKET, false, NW, TILES, NBUF>(a, nvox, st); }
+  const size_t lds = k2_lds_bytes(KSTEPS, BRACKET, a.T.ldn, TILES, NBUF);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2 kernel needs %zu B of LDS (> 160 KiB): N=%d too large", lds, a.T.N);
-  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET, PIPE && !BRACKET>;
+  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET, PIPE && !BRACKET, NW, TILES, NBUF>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (g_profiling) {
     if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
@@ -255,7 +255,7 @@ static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
   }
   FitK2Args aa = a;
   aa.stamps = g_stamps;
-  hipLaunchKernelGGL(kern, dim3(nvox), dim3(MFX_WG), lds, st, aa);
+  hipLaunchKernelGGL(kern, dim3(nvox), dim3(NW * 64), lds, st, aa);
   HIPCHK(hipGetLastError());
   if (g_profiling) {
     HIPCHK(hipEventRecord(g_ev1, st));
@@ -270,7 +270,10 @@ static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   const bool br = a.P.any_bracket != 0;
   if (M <= 64) return br ? launch_k2_t<16, true>(a, nvox, st) : launch_k2_t<16, false>(a, nvox, st);
   if (M <= 200) return br ? launch_k2_t<50, true>(a, nvox, st) : launch_k2_t<50, false>(a, nvox, st);
-  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 200 in this build (got %d)", M);
+  // long protocols: one wave per SIMD (512 registers hold the A operand), single-tile single-buffer chunks
+  if (M <= 400) return br ? launch_k2_t<100, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<100, false, false, 4, 1, 1>(a, nvox, st);
+  if (M <= 560) return br ? launch_k2_t<140, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<140, false, false, 4, 1, 1>(a, nvox, st);
+  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 560 (got %d)", M);
 }
 
 // ---- extra (voxel-independent) columns of one voxel class: [csf] + [ear_0..ear_{E-1}]
@@ -332,18 +335,18 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   return MFX_OK;
 }
 
-static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP) {
+static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf) {
   const size_t MP = (size_t)ksteps * 4;
-  size_t dbl = 2 * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + 8 * 16 * MFX_XS +
+  size_t dbl = (size_t)nbuf * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + (size_t)nw * 16 * MFX_XS +
                2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 32;
   return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
 }
 
-template <int KSTEPS, bool BRACKET>
+template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
 static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
-  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn);
+  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
-  auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET>;
+  auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // per-workgroup scratch slab: launch in chunks so the slab stays modest
   const int chunk = 2048;
@@ -353,7 +356,7 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
   a.ws = ws;
   for (int base = 0; base < nvox; base += chunk) {
     a.vox_base = base;
-    hipLaunchKernelGGL(kern, dim3(std::min(chunk, nvox - base)), dim3(MFX_XWG), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(std::min(chunk, nvox - base)), dim3(NW * 64), lds, st, a);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipFreeAsync(ws, st));
@@ -365,7 +368,9 @@ static int launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
   const bool br = a.P.any_bracket != 0;
   if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
   if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
-  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernels support M <= 200 in this build (got %d)", M);
+  if (M <= 400) return br ? launch_k2x_t<100, true, 4, 1>(a, nvox, st) : launch_k2x_t<100, false, 4, 1>(a, nvox, st);
+  if (M <= 560) return br ? launch_k2x_t<140, true, 4, 1>(a, nvox, st) : launch_k2x_t<140, false, 4, 1>(a, nvox, st);
+  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernels support M <= 560 (got %d)", M);
 }
 
 // one homogeneous voxel class (every voxel: K fascicles, has_csf, has_ear); device pointers

@@ -343,3 +343,40 @@ def test_k2_with_compartments_vs_oracle(c, e, N, V):
     assert np.array_equal(got[:, ids], ref[:, ids])
     tol = 1e-9 if not (c and e) else 1e-7     # _4up: third-party NNLS in the reference, Gram-based optimum here
     assert np.allclose(got, ref, rtol=tol, atol=1e-9)
+
+
+@pytest.mark.parametrize("dirs,c,bracket", [([100, 100, 100], 0, False), ([137, 137, 137, 137], 0, False),
+                                            ([100, 100, 100], 1, False), ([137, 137, 137, 137], 1, True)])
+def test_k2_long_protocols(dirs, c, bracket):
+    """Protocols longer than 200 measurements (M = 302 and M = 552, the HCP-MGH length): the one-wave-per-SIMD
+    variants of the fused kernels, with and without CSF, exact-G and G-bracketed."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(500 + len(dirs) + 7 * c)
+    shells = [1000, 2000, 3000, 5000][:len(dirs)]
+    sch_ms = synth.make_scheme(rng, 2 + 2 * (len(dirs) - 3), shells, dirs)
+    N, V = 40, 10
+    dic = synth.make_dictionary(rng, sch_ms, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch_ms, Z)
+    sch = sch_ms.copy()
+    if bracket:
+        nz = np.where(sch[:, 3] > 0)[0]
+        Gs = ms["Gms_un"]
+        sch[nz[::3], 3] = rng.uniform(Gs[1], Gs[-1], nz[::3].size)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    b = (orc.GAMMA_H * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3e-9)
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    Y = rng.normal(0, 500 / 30.0, (V, sch.shape[0]))
+    for v in range(V):
+        comps = [orc.interp(sch, peaks[v, :3], T)[:, rng.integers(0, N)], orc.interp(sch, peaks[v, 3:], T)[:, rng.integers(0, N)]]
+        if c:
+            comps.append(sig_csf)
+        Y[v] += 500 * np.stack(comps, 1) @ rng.dirichlet(np.ones(len(comps)))
+    Kv = np.full(V, 2)
+    cm = np.full(V, bool(c)); z = np.zeros(V, bool)
+    ref = orc.fit_batch(T, sch, Y, Kv, cm, z, peaks, 2, bool(c), False, sig_csf if c else None, None, 0, nthreads=8)
+    got = engine.fit_batch(ms.plan_for(sch), Y, Kv, cm, z, peaks, 2, bool(c), False, sig_csf if c else None, None, 0)
+    assert np.array_equal(got[:, 3:5], ref[:, 3:5])
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-9)
