@@ -61,38 +61,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MFX_BENCH_BACKEND", "nccl")     # "gloo" only for rehearsals on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    dev_index = (local_rank % ndev) if world > 1 else 0
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- dictionary tables: built on rank 0, broadcast once (RCCL over xGMI), then staged to HBM
+    ms = sch = None
     if rank == 0:
         sch, dic, ms = build_model(a.atoms)
-        blob = [ms.pack()]
-    else:
-        blob = [None]
     if world > 1:
-        # tensors go over RCCL; the small python header (shapes) rides along as an object
-        if rank == 0:
-            hdr, flat = blob[0]
-            meta = [hdr, int(flat.size), sch.shape]
-        else:
-            meta = [None, None, None]
-        dist.broadcast_object_list(meta, src=0)
-        hdr, nflat, sch_shape = meta
-        t_flat = torch.empty(nflat, dtype=torch.float64, device=dev)
-        t_sch = torch.empty(sch_shape, dtype=torch.float64, device=dev)
-        if rank == 0:
-            t_flat.copy_(torch.from_numpy(flat))
-            t_sch.copy_(torch.from_numpy(sch))
-        dist.broadcast(t_flat, src=0)
-        dist.broadcast(t_sch, src=0)
-        if rank != 0:
-            ms = mfu.MultiShellInterpolator.unpack(hdr, t_flat.cpu().numpy())
-            sch = t_sch.cpu().numpy()
+        from microstructure_fingerprinting_amd import dist as mdist
+        ms, sch = mdist.broadcast_interpolator(ms, sch, src=0, device=dev if backend == "nccl" else None)
     ms.device = dev.index or 0
     plan = engine.Plan(ms.device_tables(), scheme=sch)
     M, N = sch.shape[0], ms.num_subs
@@ -141,7 +128,7 @@ def main():
     lib.mfx_set_profiling(0)
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3

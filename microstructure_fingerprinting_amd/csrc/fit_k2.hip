@@ -26,8 +26,8 @@
 //        instruction COUNT: both operands are pre-normalised (the accumulator is the cosine c of the
 //        atom pair), the scan handles only the two-positive-weights case (16 VALU per entry); the
 //        single-active cases are represented by the two best single atoms and resolved by phase 3's
-//        family expansion; the next D2 chunk is generated and the previous chunk scanned in slices
-//        inside the MFMA k-loop (hides the L2 latency of the table loads).
+//        family expansion; the next D2 chunk is generated in slices inside the MFMA k-loop (hides the
+//        L2 latency of the table loads); no register spills (scratch traffic would show up as HBM bytes).
 //   GENERIC (protocols with G-bracketed rows, or MFX_K2_PIPE=0): straightforward chunk loop.
 #pragma once
 #include <type_traits>
@@ -171,9 +171,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     if (n < N) {
 #pragma unroll 8
       for (int m = 0; m < M; ++m) {
-        const double d = elem(k, m, n);
-        a2 += d * d;
-        ay += s_y[m] * d;
+        if constexpr (FAST) {   // ranking statistics only (the exact stage re-sums in reference order): fused ops
+          const double2 e = tab[(size_t)s_r0[k * MP + m] * ldn + n];
+          const double d = fma(e.y, s_t0[k * MP + m], e.x);
+          a2 = fma(d, d, a2);
+          ay = fma(s_y[m], d, ay);
+        } else {
+          const double d = elem(k, m, n);
+          a2 += d * d;
+          ay += s_y[m] * d;
+        }
       }
     }
     if constexpr (FAST) {
@@ -259,14 +266,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     const int rtc = rt_valid ? rt : 0;
     // A operand: this wave's 16 atoms of D1, all KSTEPS k-steps, in registers
     double afr[KSTEPS];
-    {
-      const double sc = FAST ? s_A11[rtc * 16 + lc] : 1.0;
 #pragma unroll
-      for (int kk = 0; kk < KSTEPS; ++kk) {
-        const double v = rt_valid ? elem(0, 4 * kk + lg, rtc * 16 + lc) : 0.0;
-        afr[kk] = FAST ? v * sc : v;
-      }
-    }
+    for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rtc * 16 + lc) : 0.0;
     double bp[4], bq[4];
     int bj[4];
 #pragma unroll
@@ -278,11 +279,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     if (round == 0) MFX_STAMP(4);
 
     if constexpr (FAST) {
-      double z1r[4];
+      double z1r[4], i1r[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
-      // two-positive-weights case of one accumulator entry: c = cos(atom i, atom j), z = d.y/|d|
-      auto scan_one = [&](double c, int r, int j, double z2) {
+      for (int r = 0; r < 4; ++r) {
+        z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
+        i1r[r] = s_A11[rtc * 16 + lg + 4 * r];
+      }
+      // two-positive-weights case of one accumulator entry; the D2 operand is normalised when it is
+      // generated, the D1 side here: c = cos(atom i, atom j), z = d.y/|d|
+      auto scan_one = [&](double acc_ij, int r, int j, double z2) {
+        const double c = acc_ij * i1r[r];
         const double e1 = fma(-c, z2, z1r[r]);
         const double e2 = fma(-c, z1r[r], z2);
         const double den = fma(-c, c, 1.0);
@@ -295,16 +301,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
       constexpr int NEL = (MP + 15) / 16;                                  // D2 elements per thread per chunk
       constexpr int GS = (KSTEPS - 5) / NEL > 0 ? (KSTEPS - 5) / NEL : 1;  // k-steps between two element loads
       constexpr int GD = 4;                                                // load -> use distance in k-steps
-      constexpr int SU = (KSTEPS - 2) / 8 > 0 ? (KSTEPS - 2) / 8 : 1;      // k-steps between two scan units
       constexpr int PD = 3;                                                // B operand read-ahead in k-steps
       static_assert(GS * (NEL - 1) + GD < KSTEPS, "generation slices do not fit in the k-loop");
-      static_assert(SU * 7 + 2 < KSTEPS, "scan slices do not fit in the k-loop");
       const int gc = tid & 31, gm0 = tid >> 5;
       const int* gr = s_r0 + MP;  // direction-1 descriptors
       const double* gt = s_t0 + MP;
-      d4 accP0 = {0, 0, 0, 0}, accP1 = {0, 0, 0, 0};
-      int jprev = 0;      // column (tile 0, this lane) of the accumulators waiting to be scanned
-      bool pend = false;  // wave-uniform
       for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const int n_next = (ch + 1) * 32 + gc;
@@ -313,10 +314,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
         const double2* gsrc = tab + min(n_next, NP - 1);
         const double* b0p = sB + (size_t)buf * (2 * MPS * 16) + lg * 16 + lc;
         const double* b1p = b0p + MPS * 16;
-        // statistics of the columns whose accumulators are pending
-        const double z2p0 = (pend && jprev < NP) ? s_Y2[min(jprev, NP - 1)] : 0.0;
-        const double z2p1 = (pend && jprev + 16 < NP) ? s_Y2[min(jprev + 16, NP - 1)] : 0.0;
-        const bool mma = rt_valid;  // wave-uniform
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double2 gl[3];
         double gtv[3];
@@ -350,28 +347,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
               constexpr int p = (kk - GD) / GS;
               gdst[(gm0 + 16 * p) * 16] = fma(gl[p % 3].y, gtv[p % 3], gl[p % 3].x) * gsc;
             }
-            // slice of the pending pair scan (z2p* are 0 when nothing is pending: no candidate can form)
-            if constexpr (kk >= 2 && (kk - 2) % SU == 0 && (kk - 2) / SU < 8) {
-              constexpr int u = (kk - 2) / SU;
-              if constexpr (u < 4) scan_one(accP0[u & 3], u & 3, jprev, z2p0);
-              else scan_one(accP1[u & 3], u & 3, jprev + 16, z2p1);
-            }
           });
         };
-        if (mma) body(std::true_type{}); else body(std::false_type{});
-        accP0 = acc0;
-        accP1 = acc1;
-        pend = mma;
-        jprev = ch * 32 + lc;
+        if (rt_valid) {
+          body(std::true_type{});
+          // pair scan of the two accumulator tiles (VALU work cannot hide behind FP64 MFMAs anyway)
+          const int j0 = ch * 32 + lc, j1 = j0 + 16;
+          const double z20 = (j0 < NP) ? s_Y2[min(j0, NP - 1)] : 0.0;
+          const double z21 = (j1 < NP) ? s_Y2[min(j1, NP - 1)] : 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scan_one(acc0[r], r, j0, z20);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scan_one(acc1[r], r, j1, z21);
+        } else {
+          body(std::false_type{});
+        }
         __syncthreads();
-      }
-      if (pend) {  // scan of the last computed chunk
-        const double z20 = (jprev < NP) ? s_Y2[min(jprev, NP - 1)] : 0.0;
-        const double z21 = (jprev + 16 < NP) ? s_Y2[min(jprev + 16, NP - 1)] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) scan_one(accP0[r], r, jprev, z20);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) scan_one(accP1[r], r, jprev + 16, z21);
       }
     } else {
       double A11r[4], Y1r[4], s1r[4];
