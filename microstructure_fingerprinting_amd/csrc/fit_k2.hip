@@ -261,13 +261,27 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
   const int nrounds = (ntiles + NW - 1) / NW;
 
   for (int round = 0; round < nrounds; ++round) {
-    const int rt = round * NW + wave;
-    const bool rt_valid = rt < ntiles;  // wave-uniform
+    // mode of this wave in this round: 0 idle, 1 both column tiles of every chunk, 2 / 3 only tile 0 / 1.
+    // A last round with ONE row tile left (N = 782: 49 = 6*8 + 1) is shared by waves 0 and 1 (they sit on
+    // different SIMDs): each takes one of the two column tiles -> that round costs half the MFMA time.
+    int rt = round * NW + wave;
+    int mode = (rt < ntiles) ? 1 : 0;
+    if (FAST && ntiles - round * NW == 1) {
+      rt = round * NW;
+      mode = (wave == 0) ? 2 : ((wave == 1) ? 3 : 0);
+    }
+    const bool rt_valid = mode != 0;  // wave-uniform
     const int rtc = rt_valid ? rt : 0;
     // A operand: this wave's 16 atoms of D1, all KSTEPS k-steps, in registers
     double afr[KSTEPS];
+    {
+      const double asc = FAST ? (rt_valid ? s_A11[rtc * 16 + lc] : 0.0) : 1.0;  // FAST: normalised atoms
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rtc * 16 + lc) : 0.0;
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const double v = rt_valid ? elem(0, 4 * kk + lg, rtc * 16 + lc) : 0.0;
+        afr[kk] = FAST ? v * asc : v;
+      }
+    }
     double bp[4], bq[4];
     int bj[4];
 #pragma unroll
@@ -279,16 +293,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     if (round == 0) MFX_STAMP(4);
 
     if constexpr (FAST) {
-      double z1r[4], i1r[4];
+      double z1r[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
-        i1r[r] = s_A11[rtc * 16 + lg + 4 * r];
-      }
-      // two-positive-weights case of one accumulator entry; the D2 operand is normalised when it is
-      // generated, the D1 side here: c = cos(atom i, atom j), z = d.y/|d|
-      auto scan_one = [&](double acc_ij, int r, int j, double z2) {
-        const double c = acc_ij * i1r[r];
+      for (int r = 0; r < 4; ++r) z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
+      // two-positive-weights case of one accumulator entry; both MFMA operands are normalised when they
+      // are generated: c = cos(atom i, atom j), z = d.y/|d|
+      auto scan_one = [&](double c, int r, int j, double z2) {
         const double e1 = fma(-c, z2, z1r[r]);
         const double e2 = fma(-c, z1r[r], z2);
         const double den = fma(-c, c, 1.0);
@@ -317,23 +327,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         double2 gl[3];
         double gtv[3];
-        auto body = [&](auto mma_c) {
-          constexpr bool MMA = decltype(mma_c)::value;
+        auto body = [&](auto mode_c) {
+          constexpr int MODE = decltype(mode_c)::value;
+          constexpr bool T0 = (MODE == 1 || MODE == 2), T1 = (MODE == 1 || MODE == 3);
           double bb0[PD + 1], bb1[PD + 1];
-          if constexpr (MMA) {
 #pragma unroll
-            for (int q = 0; q < PD; ++q) { bb0[q] = b0p[q * 64]; bb1[q] = b1p[q * 64]; }
+          for (int q = 0; q < PD; ++q) {
+            if constexpr (T0) bb0[q] = b0p[q * 64];
+            if constexpr (T1) bb1[q] = b1p[q * 64];
           }
           mfx_static_for<0, KSTEPS>([&](auto kc) {
             constexpr int kk = decltype(kc)::value;
-            if constexpr (MMA) {
-              if constexpr (kk + PD < KSTEPS) {
-                bb0[(kk + PD) % (PD + 1)] = b0p[(kk + PD) * 64];
-                bb1[(kk + PD) % (PD + 1)] = b1p[(kk + PD) * 64];
-              }
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb0[kk % (PD + 1)], acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb1[kk % (PD + 1)], acc1, 0, 0, 0);
+            if constexpr (kk + PD < KSTEPS) {
+              if constexpr (T0) bb0[(kk + PD) % (PD + 1)] = b0p[(kk + PD) * 64];
+              if constexpr (T1) bb1[(kk + PD) % (PD + 1)] = b1p[(kk + PD) * 64];
             }
+            if constexpr (T0) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb0[kk % (PD + 1)], acc0, 0, 0, 0);
+            if constexpr (T1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb1[kk % (PD + 1)], acc1, 0, 0, 0);
             // slice of the next chunk's generation: issue the load of element p ...
             if constexpr (kk % GS == 0 && kk / GS < NEL) {
               constexpr int p = kk / GS;
@@ -348,20 +358,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
               gdst[(gm0 + 16 * p) * 16] = fma(gl[p % 3].y, gtv[p % 3], gl[p % 3].x) * gsc;
             }
           });
-        };
-        if (rt_valid) {
-          body(std::true_type{});
-          // pair scan of the two accumulator tiles (VALU work cannot hide behind FP64 MFMAs anyway)
+          // pair scan of the accumulator tile(s) (VALU work cannot hide behind FP64 MFMAs anyway)
           const int j0 = ch * 32 + lc, j1 = j0 + 16;
-          const double z20 = (j0 < NP) ? s_Y2[min(j0, NP - 1)] : 0.0;
-          const double z21 = (j1 < NP) ? s_Y2[min(j1, NP - 1)] : 0.0;
+          if constexpr (T0) {
+            const double z20 = (j0 < NP) ? s_Y2[min(j0, NP - 1)] : 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) scan_one(acc0[r], r, j0, z20);
+            for (int r = 0; r < 4; ++r) scan_one(acc0[r], r, j0, z20);
+          }
+          if constexpr (T1) {
+            const double z21 = (j1 < NP) ? s_Y2[min(j1, NP - 1)] : 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) scan_one(acc1[r], r, j1, z21);
-        } else {
-          body(std::false_type{});
-        }
+            for (int r = 0; r < 4; ++r) scan_one(acc1[r], r, j1, z21);
+          }
+        };
+        if (mode == 1) body(std::integral_constant<int, 1>{});
+        else if (mode == 0) body(std::integral_constant<int, 0>{});
+        else if (mode == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
         __syncthreads();
       }
     } else {
