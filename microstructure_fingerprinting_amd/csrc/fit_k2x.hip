@@ -70,7 +70,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double* s_Yx = s_a2x + 2 * 16 * MFX_XS;         // [XS]
   double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
   double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
-  CandX* s_cand = (CandX*)(s_red + 32);           // [XMAXC]
+  // feasible-support tables (strides NX+1: entry NX = the support with the fixed CSF column only)
+  const int TS = NX + 1;
+  double* s_Qx = s_red + 32;                      // [XS]            supports without a fascicle atom
+  double* s_R1 = s_Qx + MFX_XS;                   // [NW][16][TS]    supports {d1_i} + extras
+  double* s_R2 = s_R1 + NW * 16 * TS;             // [2][16][TS]     supports {d2_j} + extras
+  CandX* s_cand = (CandX*)(s_R2 + 2 * 16 * TS);   // [XMAXC]
   int* s_r0 = (int*)(s_cand + MFX_XMAXC);         // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;
   int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);
@@ -105,6 +110,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     s_Yx[tid] = s;
   }
   if (tid == 64) s_red[16] = mfx_np_sumsq(s_y, M);  // _4up: min_obj starts at np.sum(y**2)
+  __syncthreads();
+  const bool HASF = (Kp == 4);   // a fixed CSF column (index 0) besides the varying extra column
+  const int x0 = HASF ? 1 : 0;   // first varying extra column
+  if (tid < ntup) {              // supports made of extra columns only
+    const int cx = x0 + tid;
+    double q = pos1(s_Gxx[cx * MFX_XS + cx], s_Yx[cx]);
+    if (HASF) q = fmax(q, fmax(pos1(s_Gxx[0], s_Yx[0]), pos2(s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], s_Yx[0], s_Yx[cx])));
+    s_Qx[tid] = q;
+  }
 
   auto elem = [&](int k, int m, int n) -> double {
     if (BRACKET) {
@@ -143,14 +157,28 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   __syncthreads();
   const double y_sq = (Kp == 4) ? s_red[16] : y_sq_seq;
 
+  // best support {atom} + subset of {fixed, x_t} with a non-negative solution, t = TS-1: {atom, fixed} only
+  auto atom_supports = [&](double a11, double y1, const double* ax /* atom . extras, stride 1 */, int t) -> double {
+    if (t == NX) return HASF ? pos2(a11, ax[0], s_Gxx[0], y1, s_Yx[0]) : 0.0;
+    if (t >= ntup) return 0.0;
+    const int cx = x0 + t;
+    double r = pos2(a11, ax[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[cx]);
+    if (HASF) r = fmax(r, pos3(a11, ax[0], ax[cx], s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[0], s_Yx[cx]));
+    return r;
+  };
   auto gen_chunk = [&](int ch, int buf) {
     const int c = tid & 15, m0 = tid >> 4;  // WG/16 row groups
     const int n = ch * 16 + c;
     double* dst = sB + (size_t)buf * (MP * 16) + c;
     for (int m = m0; m < MP; m += WG / 16) dst[m * 16] = elem(1, m, n);
-    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms
+    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms and their one-atom supports
       const int cc = tid / MFX_XS, e = tid - cc * MFX_XS;
-      s_a2x[(buf * 16 + cc) * MFX_XS + e] = wsA[((size_t)NP + ch * 16 + cc) * MFX_XS + e];
+      const double* ax = wsA + ((size_t)NP + ch * 16 + cc) * MFX_XS;
+      s_a2x[(buf * 16 + cc) * MFX_XS + e] = ax[e];
+      if (e < TS) {
+        const int n = ch * 16 + cc;
+        s_R2[(buf * 16 + cc) * TS + e] = (n < N) ? atom_supports(s_A22[n], s_Y2[n], ax, e) : 0.0;
+      }
     }
   };
 
@@ -165,8 +193,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) afr[kk] = rt_valid ? elem(0, 4 * kk + lg, rt * 16 + lc) : 0.0;
     // stage this wave's A1x rows
-    if (rt_valid)
+    if (rt_valid) {
       for (int q = lane; q < 16 * MFX_XS; q += 64) s_a1x[wave * 16 * MFX_XS + q] = wsA[((size_t)rt * 16) * MFX_XS + q];
+      for (int q = lane; q < 16 * TS; q += 64) {
+        const int il = q / TS, t = q - il * TS, i = rt * 16 + il;
+        s_R1[(wave * 16 + il) * TS + t] = (i < N) ? atom_supports(s_A11[i], s_Y1[i], wsA + (size_t)i * MFX_XS, t) : 0.0;
+      }
+    }
     double bs[4];
     int bj[4], be[4];
 #pragma unroll
@@ -189,25 +222,83 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bp[kk * 64], acc, 0, 0, 0);
         const int j = ch * 16 + lc;
         if (j < N) {
-          const double A22 = s_A22[j], Y2 = s_Y2[j];
+          // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports
+          // whose unconstrained solution is non-negative.  Supports without both fascicle atoms come from
+          // the tables; per pair the {1,2}(+fixed) block is eliminated once (LDL^T), per extra column only
+          // the last row is added -> ~30 VALU per tuple instead of a full 3x3/4x4 solve with fallbacks.
+          const double a22 = s_A22[j], y2 = s_Y2[j];
+          const double s2 = pos1(a22, y2);
           const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
+          const double* R2 = s_R2 + (buf * 16 + lc) * TS;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int il = lg + 4 * r;
             const int i = rt * 16 + il;
             if (i < N) {
-              const double A11 = s_A11[i], Y1 = s_Y1[i], A12 = acc[r];
+              const double a11 = s_A11[i], y1 = s_Y1[i], a12 = acc[r];
               const double* a1x = s_a1x + (wave * 16 + il) * MFX_XS;
+              const double* R1 = s_R1 + (wave * 16 + il) * TS;
+              // LDL^T of the {1,2} block
+              const double ip1 = mfx_rcp(a11);
+              const double l21 = a12 * ip1;
+              const double p2 = fma(-l21, a12, a22);
+              const double u2 = fma(-l21, y1, y2);
+              const bool ok2 = p2 > 1e-8 * a22;
+              const double ip2 = mfx_rcp(ok2 ? p2 : 1.0);
+              const double v1 = y1 * ip1, v2 = u2 * ip2;
+              const double S2u = fma(u2, v2, y1 * v1);
+              const double w1p = fma(-l21, v2, v1);
+              // best support inside {1,2}: both atoms, or the better single atom
+              double base = fmax((y1 > 0.0) ? y1 * v1 : 0.0, s2);
+              base = (ok2 && w1p >= 0.0 && v2 >= 0.0) ? fmax(base, S2u) : base;
+              // fixed (CSF) column: extend the elimination by one row
+              double l31 = 0.0, b23 = 0.0, l32 = 0.0, ip3 = 0.0, u3 = 0.0, v3 = 0.0, S3u = 0.0;
+              bool ok3 = false;
+              if (HASF) {
+                const double a1f = a1x[0], a2f = a2x[0], aff = s_Gxx[0], yf = s_Yx[0];
+                l31 = a1f * ip1;
+                b23 = fma(-l21, a1f, a2f);
+                l32 = b23 * ip2;
+                const double p3 = fma(-l32, b23, fma(-l31, a1f, aff));
+                u3 = fma(-l32, u2, fma(-l31, y1, yf));
+                ok3 = ok2 && (p3 > 1e-8 * aff);
+                ip3 = mfx_rcp(ok3 ? p3 : 1.0);
+                v3 = u3 * ip3;
+                S3u = fma(u3, v3, S2u);
+                const double w2f = fma(-l32, v3, v2);
+                const double w1f = fma(-l31, v3, fma(-l21, w2f, v1));
+                base = fmax(base, fmax(R1[NX], R2[NX]));                  // {1,f}, {2,f}
+                base = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(base, S3u) : base;  // {1,2,f}
+              }
               for (int t = 0; t < ntup; ++t) {
-                double s;
-                if (Kp == 3) {
-                  s = score3(A11, A12, a1x[t], A22, a2x[t], s_Gxx[t * MFX_XS + t], Y1, Y2, s_Yx[t]);
-                } else {
-                  const int ce = 1 + t;
-                  const double g[10] = {A11, A12, a1x[0], a1x[ce], A22, a2x[0], a2x[ce], s_Gxx[0], s_Gxx[ce],
-                                        s_Gxx[ce * MFX_XS + ce]};
-                  const double yy[4] = {Y1, Y2, s_Yx[0], s_Yx[ce]};
-                  s = score4(g, yy);
+                const int cx = x0 + t;
+                const double a1e = a1x[cx], a2e = a2x[cx], aee = s_Gxx[cx * MFX_XS + cx], ye = s_Yx[cx];
+                double s = fmax(base, fmax(s_Qx[t], fmax(R1[t], R2[t])));
+                // support {1,2,x}: last row of the LDL^T on top of the {1,2} block
+                const double m1 = a1e * ip1;
+                const double t2 = fma(-m1, a12, a2e);
+                const double m2 = t2 * ip2;
+                {
+                  const double p3x = fma(-m2, t2, fma(-m1, a1e, aee));
+                  const double u3x = fma(-m2, u2, fma(-m1, y1, ye));
+                  const bool okx = ok2 && (p3x > 1e-8 * aee);
+                  const double w3 = u3x * mfx_rcp(okx ? p3x : 1.0);
+                  const double w2 = fma(-m2, w3, v2);
+                  const double w1 = fma(-m1, w3, fma(-l21, w2, v1));
+                  s = (okx && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0) ? fmax(s, fma(u3x, w3, S2u)) : s;
+                }
+                if (HASF) {  // support {1,2,f,x}: last row on top of the {1,2,f} block
+                  const double afe = s_Gxx[cx];
+                  const double t3 = fma(-m2, b23, fma(-m1, a1x[0], afe));
+                  const double m3 = t3 * ip3;
+                  const double p4 = fma(-m3, t3, fma(-m2, t2, fma(-m1, a1e, aee)));
+                  const double u4 = fma(-m3, u3, fma(-m2, u2, fma(-m1, y1, ye)));
+                  const bool ok4 = ok3 && (p4 > 1e-8 * aee);
+                  const double w4 = u4 * mfx_rcp(ok4 ? p4 : 1.0);
+                  const double w3 = fma(-m3, w4, v3);
+                  const double w2 = fma(-m2, w4, fma(-l32, w3, v2));
+                  const double w1 = fma(-m1, w4, fma(-l31, w3, fma(-l21, w2, v1)));
+                  s = (ok4 && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0 && w4 >= 0.0) ? fmax(s, fma(u4, w4, S3u)) : s;
                 }
                 if (s > bs[r]) { bs[r] = s; bj[r] = j; be[r] = t; }
               }

@@ -335,16 +335,17 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   return MFX_OK;
 }
 
-static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf) {
+static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf, int NX) {
   const size_t MP = (size_t)ksteps * 4;
   size_t dbl = (size_t)nbuf * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + (size_t)nw * 16 * MFX_XS +
+               MFX_XS + (size_t)(nw + 2) * 16 * (NX + 1) +
                2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 32;
   return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
 }
 
 template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
 static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
-  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF);
+  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, a.X.NX);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
   auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -172,3 +172,29 @@ __device__ inline void nnls_gram_subsets(int n, const double* g, const double* y
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// building blocks of the feasible-support ranking used by fit_k2x.hip: score of ONE support if its
+// unconstrained least-squares solution is non-negative, else 0 (the NNLS optimum of a tuple is the
+// maximum of these over all supports)
+__device__ __forceinline__ double mfx_rcp(double x) {  // 1/x to ~1 ulp without the IEEE division sequence
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double pos1(double a, double y) { return (y > 0.0 && a > 0.0) ? (y * y) / a : 0.0; }
+__device__ __forceinline__ double pos2(double a11, double a12, double a22, double y1, double y2) {
+  const double d1 = a22 * y1 - a12 * y2, d2 = a11 * y2 - a12 * y1, det = a11 * a22 - a12 * a12;
+  return (d1 >= 0.0 && d2 >= 0.0 && det > 1e-8 * (a11 * a22)) ? (y1 * d1 + y2 * d2) / det : 0.0;
+}
+__device__ __forceinline__ double pos3(double a11, double a12, double a13, double a22, double a23, double a33,
+                                       double y1, double y2, double y3) {
+  const double c11 = a22 * a33 - a23 * a23, c12 = a13 * a23 - a12 * a33, c13 = a12 * a23 - a13 * a22;
+  const double c22 = a11 * a33 - a13 * a13, c23 = a12 * a13 - a11 * a23, c33 = a11 * a22 - a12 * a12;
+  const double det = a11 * c11 + a12 * c12 + a13 * c13;
+  const double D1 = y1 * c11 + y2 * c12 + y3 * c13;
+  const double D2 = y1 * c12 + y2 * c22 + y3 * c23;
+  const double D3 = y1 * c13 + y2 * c23 + y3 * c33;
+  return (det > 1e-12 * (a11 * a22 * a33) && D1 >= 0.0 && D2 >= 0.0 && D3 >= 0.0) ? (y1 * D1 + y2 * D2 + y3 * D3) / det : 0.0;
+}
