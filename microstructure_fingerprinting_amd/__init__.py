@@ -9,4 +9,4 @@ rensonnetg/microstructure_fingerprinting (``MFModel.fit`` / ``mf_utils``).
 __version__ = "0.1.0"
 
 from . import mf_utils  # noqa: E402,F401
-from .mf import MFModel, MFModelFit  # noqa: E402,F401
+from .mf import MFModel, MFModelFit, cleanup_2fascicles  # noqa: E402,F401

@@ -27,6 +27,117 @@ def _load_volume(x):
     return x, None
 
 
+# ---------------------------------------------------------------------------------------------
+# peak clean-up ahead of the fit (post-processing of a 2-tensor / 2-peak estimate)
+# ---------------------------------------------------------------------------------------------
+CLEANUP_RATIO = 2.5        # dominant/minor weight ratio beyond which the minor fascicle is dropped ...
+CLEANUP_W_KEEP = 0.20      # ... unless its own weight reaches this value
+CLEANUP_W_SMALL = 0.075    # absolute weight under which a fascicle is always dropped
+CLEANUP_ANG_MIN = 15       # crossing angle [deg] under which two peaks are merged
+
+
+def _directions_from(mu, peakmode):
+    """(n, 2|3|6) orientation descriptors -> (n, 3) direction vectors."""
+    if peakmode == 'colat_longit':
+        st = np.sin(mu[..., 0])
+        return np.stack([st * np.cos(mu[..., 1]), st * np.sin(mu[..., 1]), np.cos(mu[..., 0])], axis=-1)
+    if peakmode == 'peaks':
+        return np.array(mu, dtype=np.float64)
+    return mfu.DT_vec_to_peaks(mu, 'column')
+
+
+def cleanup_2fascicles(frac1, frac2, peakmode, mu1, mu2, mask, frac12=None):
+    """Select 0, 1 or 2 of two detected fascicle orientations per voxel (same arguments, thresholds and
+    results as ref mf.py:36-335; NeuroImage 184 (2019) 964-980).
+
+    Per mask voxel, in this order: peaks closer than 15 deg are merged into population 0 (sign-aware sum,
+    weights added); a population more than 2.5x lighter than the other one and lighter than 0.20 is
+    dropped (population 1 moves to slot 0 when population 0 goes); populations lighter than 0.075 are
+    dropped; the survivors are ordered by descending weight.  Returns ``(peaks_out, num_fasc_out)`` with
+    shapes ``mask.shape + (6,)`` and ``mask.shape``."""
+    if (frac1 is None or frac2 is None) and frac12 is None:
+        raise ValueError("If fractions of first and second fascicles set to None, argument frac12 is required "
+                         "to specify both fractions simultanously. A total of 6 arguments should be passed, not 5.")
+    mask = _load_volume(mask)[0]
+    frac1 = _load_volume(frac1)[0]
+    frac2 = _load_volume(frac2)[0]
+    if frac12 is not None:
+        frac12 = _load_volume(frac12)[0]
+        if frac12.shape[-1] < 2:
+            raise ValueError("Last dimension of frac12 should have size at least 2.")
+        if frac12.shape[mask.ndim] == 1:           # (nx, ny, nz, 1, 2)
+            frac1, frac2 = frac12[..., 0, 0], frac12[..., 0, 1]
+        else:
+            frac1, frac2 = frac12[..., 0], frac12[..., 1]
+    if frac1.shape != mask.shape:
+        raise ValueError("frac1 should have the same shape as mask")
+    if frac2.shape != mask.shape:
+        raise ValueError("frac2 should have the same shape as mask")
+    mu1 = _load_volume(mu1)[0]
+    mu2 = _load_volume(mu2)[0]
+    width = {'colat_longit': 2, 'peaks': 3, 'tensor': 6}.get(peakmode)
+    if width is None:
+        raise ValueError('Unknown peak mode %s' % peakmode)
+    if peakmode == 'tensor':                        # tensor files are often (nx, ny, nz, 1, 6)
+        if mu1.shape[mask.ndim] == 1:
+            mu1 = mu1[..., 0, :]
+        if mu2.shape[mask.ndim] == 1:
+            mu2 = mu2[..., 0, :]
+    if mu1.shape[-1] != width or mu2.shape[-1] != width:
+        raise ValueError("In '%s' peak mode, last dimension of mu1 and mu2 should have size %d. Detected %d and %d."
+                         % (peakmode, width, mu1.shape[-1], mu2.shape[-1]))
+
+    roi = mask > 0
+    n = int(np.sum(roi))
+    f = np.stack([frac1[roi], frac2[roi]], axis=1).astype(np.float64)      # weights of slots 0 / 1
+    p = [_directions_from(mu1[roi], peakmode), _directions_from(mu2[roi], peakmode)]
+    count = np.full(n, 2.0)
+
+    def drop(slot, where):
+        p[slot][where] = 0.0
+        f[where, slot] = 0.0
+
+    # 1. merge nearly parallel peaks into slot 0
+    dp = np.sum(p[0] * p[1], axis=-1)
+    merge = np.abs(np.clip(dp, -1, 1)) > np.cos(CLEANUP_ANG_MIN * np.pi / 180)
+    if np.any(merge):
+        summed = p[0][merge] + p[1][merge] * np.sign(dp[merge])[:, np.newaxis]
+        p[0][merge] = summed / np.sqrt(np.sum(summed ** 2, axis=1))[:, np.newaxis]
+        f[merge, 0] = frac1[roi][merge] + frac2[roi][merge]
+        drop(1, merge)
+        count[merge] = 1
+    # 2. relatively small population 0: population 1 takes its slot
+    rel0 = (f[:, 1] > CLEANUP_RATIO * f[:, 0]) & (f[:, 0] < CLEANUP_W_KEEP)
+    if np.any(rel0):
+        p[0][rel0] = p[1][rel0]
+        f[rel0, 0] = f[rel0, 1]
+        drop(1, rel0)
+        count[rel0] = (f[rel0, 0] > 0) * 1
+    # 3. relatively small population 1: dropped, weight not transferred
+    rel1 = (f[:, 0] > CLEANUP_RATIO * f[:, 1]) & (f[:, 1] < CLEANUP_W_KEEP)
+    if np.any(rel1):
+        drop(1, rel1)
+        count[rel1] = (f[rel1, 0] > 0) * 1
+    # 4./5. small absolute weights
+    abs0 = f[:, 0] < CLEANUP_W_SMALL
+    if np.any(abs0):
+        drop(0, abs0)
+        count[abs0] = count[abs0] - 1
+    abs1 = f[:, 1] < CLEANUP_W_SMALL
+    if np.any(abs1):
+        drop(1, abs1)
+        count[abs1] = (f[abs1, 0] > 0) * 1
+    # 6. heavier population first; the reference's reversed ascending argsort puts slot 1 first on ties
+    swap = (f[:, 1] >= f[:, 0])[:, np.newaxis]
+    peaks = np.concatenate([np.where(swap, p[1], p[0]), np.where(swap, p[0], p[1])], axis=1)
+
+    peaks_out = np.zeros(mask.shape + (6,))
+    peaks_out[roi] = peaks
+    num_fasc_out = np.zeros(mask.shape)
+    num_fasc_out[roi] = count
+    return peaks_out, num_fasc_out
+
+
 class MFModel():
     r"""Microstructure Fingerprinting model (ref:464-1051)."""
     MAX_FASC = 2          # ref:467
@@ -129,14 +240,8 @@ class MFModel():
                 else:
                     if a_i.shape[mask_arr.ndim] == 1:
                         a_i = a_i[(slice(None),) * mask_arr.ndim + (0, slice(None))]
-                    v = a_i[roi, :]       # NIfTI 'column' order of the upper triangle: xx xy yy xz yz zz
-                    T = np.zeros((ROI_size, 3, 3))
-                    T[:, 0, 0], T[:, 0, 1], T[:, 0, 2] = v[:, 0], v[:, 1], v[:, 3]
-                    T[:, 1, 0], T[:, 1, 1], T[:, 1, 2] = v[:, 1], v[:, 2], v[:, 4]
-                    T[:, 2, 0], T[:, 2, 1], T[:, 2, 2] = v[:, 3], v[:, 4], v[:, 5]
-                    d, eigv = np.linalg.eigh(T)
-                    nz = (np.abs(d)[..., -1] > 0)[:, np.newaxis]
-                    peaks_roi[:, 3 * i:3 * i + 3] = eigv[..., -1] * nz   # principal eigenvector, 0 for zero tensors
+                    # NIfTI 'column' order of the upper triangle; principal eigenvector, 0 for zero tensors
+                    peaks_roi[:, 3 * i:3 * i + 3] = mfu.DT_vec_to_peaks(a_i[roi, :], 'column')
             peaks_roi = np.ascontiguousarray(peaks_roi[:, :3 * maxfasc])
             if peaks_roi.shape[1] < 3 * maxfasc:
                 peaks_roi = np.concatenate([peaks_roi, np.zeros((ROI_size, 3 * maxfasc - peaks_roi.shape[1]))], axis=1)

@@ -434,6 +434,94 @@ def get_PGSE_scheme_from_bval_bvec_dense(sch_mat_dense, bvals, bvecs, Gtol=1e-3)
     return sch
 
 
+# ---------------------------------------------------------------------------------------------
+# diffusion-tensor <-> peak helpers (orientation inputs of MFModel.fit / cleanup_2fascicles)
+# ---------------------------------------------------------------------------------------------
+# position of each upper-triangle element (row, col) in the 6-vector, per storage convention
+_DT_ORDER = {
+    'row':      ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)),     # xx xy xz yy yz zz  (.nrrd)
+    'column':   ((0, 0), (0, 1), (1, 1), (0, 2), (1, 2), (2, 2)),     # xx xy yy xz yz zz  (NIfTI)
+    'diagonal': ((0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)),     # xx yy zz xy yz xz
+}
+
+
+def _dt_order(order):
+    try:
+        return _DT_ORDER[order]
+    except (KeyError, TypeError):
+        raise ValueError('Unknown order "%s".' % (order,))
+
+
+def DT_array_to_vec(DT, order='row'):
+    """(..., 3, 3) symmetric tensors -> (..., 6) vectors in the given element order (ref:865-898)."""
+    DT = np.asarray(DT)
+    if DT.ndim < 2:
+        raise ValueError('DT should have at least 2 dimensions. Detected %d.' % DT.ndim)
+    if DT.shape[-2:] != (3, 3):
+        raise ValueError('Last 2 dimensions of DT should be (3, 3). Detected (%d, %d).' % DT.shape[-2:])
+    pos = _dt_order(order)
+    return np.stack([DT[..., r, c] for (r, c) in pos], axis=-1)
+
+
+def DT_vec_to_2Darray(DT_vec, order):
+    """(..., 6) vectors -> (..., 3, 3) symmetric tensors (ref:901-957)."""
+    DT_vec = np.asarray(DT_vec)
+    if DT_vec.shape[-1] != 6:
+        raise ValueError("Last dimension of input should have size 6, detected %d." % DT_vec.shape[-1])
+    pos = _dt_order(order)
+    out = np.zeros(DT_vec.shape[:-1] + (3, 3))
+    for e, (r, c) in enumerate(pos):
+        out[..., r, c] = DT_vec[..., e]
+        out[..., c, r] = DT_vec[..., e]
+    return out
+
+
+def DT_vec_to_peaks(DT_vec, order, mask=None):
+    """Unit principal eigenvector of each tensor, zero vector for an all-zero tensor (ref:960-1019)."""
+    DT_vec = np.asarray(DT_vec)
+    was_1d = DT_vec.ndim == 1
+    if DT_vec.ndim < 2:
+        DT_vec = np.atleast_2d(DT_vec)
+    if DT_vec.shape[-1] != 6:
+        raise ValueError('DT_vec should have size 6 along last dimension. Detected %d.' % (DT_vec.shape[-1],))
+    if mask is None:
+        mask = np.ones(DT_vec.shape[:-1], dtype=bool)
+    mask = np.asarray(mask)
+    if mask.ndim != DT_vec.ndim - 1:
+        raise ValueError('mask should have %d dimension(s) since DT_vec has %d, detected %d instead.'
+                         % (DT_vec.ndim - 1, DT_vec.ndim, mask.ndim))
+    sel = mask > 0
+    lam, vec = np.linalg.eigh(DT_vec_to_2Darray(DT_vec[sel, :], order))    # ascending eigenvalues
+    keep = (np.abs(lam[..., -1]) > 0)[:, np.newaxis]
+    peaks = np.zeros(mask.shape + (3,))
+    peaks[sel] = vec[..., -1] * keep
+    return np.squeeze(peaks) if was_1d else peaks
+
+
+def peaks_to_DT_vec(peaks, order, lam_par=2e-3, lam_perp=0.1e-3):
+    """Stick-like tensors ``lam_par v v' + lam_perp (I - v v')`` for display (ref:1022-1135).
+
+    The reference draws a random perpendicular pair (p1, p2) and sums ``lam_perp (p1 p1' + p2 p2')``;
+    for any orthonormal completion that sum is ``lam_perp (I - v v')``, which is what is formed here
+    (same tensor up to rounding, and deterministic).  Returns a list with one (..., 6) array per
+    peak; like the reference, non-zero input peaks are normalised in place."""
+    if peaks.ndim < 2:
+        raise ValueError('peaks array should have at least 2 dimensions. Detected %d.' % peaks.ndim)
+    if peaks.shape[-1] != 3:
+        raise ValueError('Last dimension of peaks should have size 3, detected %d.' % (peaks.shape[-1]))
+    if lam_par < lam_perp:
+        raise ValueError('Parallel diffusivity should be greater than or equal to perpendicular diffusivity.')
+    pos = _dt_order(order)
+    nrm = np.sqrt(np.sum(peaks ** 2, axis=-1))
+    nz = nrm > 0
+    peaks[nz, :] = peaks[nz, :] / nrm[nz][:, np.newaxis]
+    v = peaks[nz, :]
+    DT = (lam_par - lam_perp) * v[:, :, np.newaxis] * v[:, np.newaxis, :] + lam_perp * np.eye(3)
+    tens = np.zeros(peaks.shape[:-1] + (6,))
+    tens[nz, :] = np.stack([DT[:, r, c] for (r, c) in pos], axis=-1)
+    return [tens[..., k, :] for k in range(peaks.shape[-2])]
+
+
 def loadmat(filename):
     """``scipy.io.loadmat`` with MATLAB structs converted to nested dicts (ref:3026-3087)."""
     import scipy.io

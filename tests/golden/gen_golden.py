@@ -369,13 +369,102 @@ def gen_c2_small(mfu, mfmod):
     print("fit_c2_small.npz written")
 
 
+def gen_inputs(mfu, mfmod):
+    """Input-normalisation callers of the path, executed by the reference:
+    bvals/bvecs -> scheme (mfu:2197-2300), tensors / colat-longit -> peaks inside MFModel.fit (mf.py:723-800),
+    scheme file import (mfu:2128-2192)."""
+    rng = np.random.default_rng(2024)
+    out = {}
+    # UKBB fixture: subject bvals/bvecs snapped onto the dense scheme
+    dense = mfu.import_PGSE_scheme(os.path.join(FIX, "ukbb_scheme_90_dirs.scheme"))
+    bvals = np.loadtxt(os.path.join(FIX, "1000521_bvals.txt"))
+    bvecs = np.loadtxt(os.path.join(FIX, "1000521_bvecs.txt"))
+    out["uk_dense"] = dense
+    out["uk_bvals"], out["uk_bvecs"] = bvals, bvecs
+    out["uk_scheme_from_bvals"] = mfu.get_PGSE_scheme_from_bval_bvec_dense(dense, bvals, bvecs, 1e-3)
+    out["hcp_scheme"] = mfu.import_PGSE_scheme(os.path.join(FIX, "hcp_mgh_1003.scheme1"))
+    # MFModel.fit through tensors=, colat_longit= and bvals/bvecs on a synthetic model
+    sch_ms = synth_scheme(rng, 1, [1000, 2000], [24, 25])
+    N, E = 12, 2
+    md = make_model_dict(rng, sch_ms, N, E)
+    model = mfmod.MFModel(dict(md))
+    V = 10
+    d1, d2 = unit(rng, V), unit(rng, V)
+    ms = model.ms_interpolator
+    Y = np.zeros((V, sch_ms.shape[0]))
+    for v in range(V):
+        A1 = mfu.interp_PGSE_from_multishell(sch_ms, d1[v], msinterp=ms)
+        A2 = mfu.interp_PGSE_from_multishell(sch_ms, d2[v], msinterp=ms)
+        Y[v] = 300 * A1[:, rng.integers(0, N)] + 200 * A2[:, rng.integers(0, N)] + rng.normal(0, 10, sch_ms.shape[0])
+    # tensors with principal eigenvector d (NIfTI 'column' order xx xy yy xz yz zz), shape (V, 1, 6) and (V, 6)
+    def tens(d, lam=(1.7e-3, 0.4e-3, 0.3e-3)):
+        T = np.zeros((d.shape[0], 6))
+        for v in range(d.shape[0]):
+            e1 = d[v]; tmp = np.cross(e1, [0.3, 0.5, 0.8]); e2 = tmp / np.linalg.norm(tmp); e3 = np.cross(e1, e2)
+            Dm = lam[0] * np.outer(e1, e1) + lam[1] * np.outer(e2, e2) + lam[2] * np.outer(e3, e3)
+            T[v] = [Dm[0, 0], Dm[0, 1], Dm[1, 1], Dm[0, 2], Dm[1, 2], Dm[2, 2]]
+        return T
+    T1, T2 = tens(d1)[:, None, :], tens(d2)
+    gam = GAM
+    bv = (gam * sch_ms[:, 3] * sch_ms[:, 5]) ** 2 * (sch_ms[:, 4] - sch_ms[:, 5] / 3) / 1e6
+    fit_t = model.fit(Y, np.ones(V), 2, tensors=[T1, T2], bvals=bv, bvecs=sch_ms[:, :3].T.copy(), verbose=0)
+    th1 = np.arccos(d1[:, 2]); ph1 = np.arctan2(d1[:, 1], d1[:, 0])
+    fit_c = model.fit(Y, np.ones(V), 1, colat_longit=np.stack([th1, ph1], 1), pgse_scheme=sch_ms, verbose=0)
+    out.update({"m_sch_ms": sch_ms, "m_dictionary": md["dictionary"], "m_rad": md["rad"], "m_fin": md["fin"],
+                "m_DIFF_ear": md["DIFF_ear"], "m_Y": Y, "m_T1": T1, "m_T2": T2, "m_bvals": bv, "m_bvecs": sch_ms[:, :3].T.copy(),
+                "m_colat": np.stack([th1, ph1], 1), "t_names": np.array(fit_t.param_names), "c_names": np.array(fit_c.param_names)})
+    for p in fit_t.param_names:
+        out["t_" + p] = getattr(fit_t, p)
+    for p in fit_c.param_names:
+        out["c_" + p] = getattr(fit_c, p)
+    np.savez_compressed(os.path.join(OUT, "input_cases.npz"), **out)
+    print("input_cases.npz written")
+
+
+def gen_cleanup(mfu, mfmod):
+    """cleanup_2fascicles (mf.py:36-335) in its three peak modes + DT helper round trips (mfu:865-1135)."""
+    rng = np.random.default_rng(99)
+    shape = (6, 5, 4)
+    n = int(np.prod(shape))
+    mask = (rng.uniform(size=shape) > 0.15).astype(float)
+    # weights drawn to hit every branch: tiny, lopsided, comparable, tied
+    f1 = rng.choice([0.0, 0.03, 0.07, 0.1, 0.19, 0.3, 0.5, 0.8], size=shape) + rng.uniform(0, 0.01, shape) * (rng.uniform(size=shape) > 0.3)
+    f2 = rng.choice([0.0, 0.03, 0.07, 0.1, 0.19, 0.3, 0.5, 0.8], size=shape) + rng.uniform(0, 0.01, shape) * (rng.uniform(size=shape) > 0.3)
+    d1 = unit(rng, n).reshape(shape + (3,))
+    d2 = unit(rng, n).reshape(shape + (3,))
+    close = rng.uniform(size=shape) < 0.3           # crossing angle below / around 15 deg, both signs
+    pert = d1 + 0.25 * rng.uniform(size=shape + (1,)) * unit(rng, n).reshape(shape + (3,))
+    pert /= np.linalg.norm(pert, axis=-1, keepdims=True)
+    d2[close] = (pert * rng.choice([-1.0, 1.0], size=shape + (1,)))[close]
+    out = {"mask": mask, "f1": f1, "f2": f2, "d1": d1, "d2": d2}
+    pk, nf = mfmod.cleanup_2fascicles(f1, f2, 'peaks', d1.copy(), d2.copy(), mask)
+    out["peaks_pk"], out["peaks_nf"] = pk, nf
+    cl1 = np.stack([np.arccos(d1[..., 2]), np.arctan2(d1[..., 1], d1[..., 0])], -1)
+    cl2 = np.stack([np.arccos(d2[..., 2]), np.arctan2(d2[..., 1], d2[..., 0])], -1)
+    pk, nf = mfmod.cleanup_2fascicles(None, None, 'colat_longit', cl1, cl2, mask, frac12=np.stack([f1, f2], -1)[..., None, :])
+    out["cl1"], out["cl2"], out["colat_pk"], out["colat_nf"] = cl1, cl2, pk, nf
+    T = mfu.peaks_to_DT_vec(np.stack([d1, d2], axis=-2).copy(), 'column')
+    zero = rng.uniform(size=shape) < 0.1            # zero tensors -> zero peaks
+    T[1][zero] = 0
+    pk, nf = mfmod.cleanup_2fascicles(f1, f2, 'tensor', T[0][..., None, :], T[1], mask)
+    out["T1"], out["T2"], out["tensor_pk"], out["tensor_nf"] = T[0], T[1], pk, nf
+    for order in ("row", "column", "diagonal"):
+        A = mfu.DT_vec_to_2Darray(T[0], order)
+        out["dt2d_" + order] = A
+        out["dtvec_" + order] = mfu.DT_array_to_vec(A, order)
+        out["dtpk_" + order] = mfu.DT_vec_to_peaks(T[1], order, mask)
+    np.savez_compressed(os.path.join(OUT, "cleanup_cases.npz"), **out)
+    print("cleanup_cases.npz written; num_fasc histogram", np.bincount(out["peaks_nf"].astype(int).ravel()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     mfu, mfmod = import_reference()
     todo = {"solver": lambda: gen_solver(mfu), "rotation": lambda: gen_rotation(mfu),
-            "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod)}
+            "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod),
+            "inputs": lambda: gen_inputs(mfu, mfmod), "cleanup": lambda: gen_cleanup(mfu, mfmod)}
     for k, fn in todo.items():
         if a.only in (None, k):
             fn()
