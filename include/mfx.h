@@ -106,6 +106,23 @@ int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peak
 int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const int64_t* dicsizes, int Kp, const double* y,
                          double* w, int64_t* sub, int64_t* tot, double* min_obj, double* y_rec);
 
+/* ---- Monte-Carlo signal synthesis (dictionary generation, upstream of fitting): replaces
+ * monte_carlo_average(sim_phases, delta_mapping, gscaling, Dscaling, num_spins) (mf_utils.py:2758-2810),
+ * the kernel under get_PGSE_from_phases (mf_utils.py:2813-3015).
+ *   signal[i] = (1/num_spins) * sum_l cos(Dscaling * sum_n gscaling[i,n] * phases[delta_mapping[i]*num_spins + l, n])
+ * sim_phases [n_entries x dim] row-major on the host (dim 1..3); delta_mapping int64[n_seq]; gscaling
+ * [n_seq x dim] row-major; signal double[n_seq] (host).  MFX_ERR_ARG if a mapping points outside the
+ * phase table (the reference would index out of bounds).                                            */
+int mfx_monte_carlo_average(const double* sim_phases, int64_t n_entries, int dim, const int64_t* delta_mapping,
+                            const double* gscaling, double Dscaling, int64_t num_spins, int64_t n_seq,
+                            double* signal, int device);
+/* Same with the phase table already on the current device, any layout: element (entry e, dimension d)
+ * is d_phases[e*spin_stride + d*dim_stride] (row-major: dim,1; one plane per phase file: 1,n_entries).
+ * delta_mapping, gscaling and signal stay host arrays (n_seq is small).                           */
+int mfx_monte_carlo_average_dev(const double* d_phases, int64_t n_entries, int64_t spin_stride, int64_t dim_stride,
+                                int dim, const int64_t* delta_mapping, const double* gscaling, double Dscaling,
+                                int64_t num_spins, int64_t n_seq, double* signal, void* stream);
+
 /* Timing hook for bench.py: average device time (ms) of the dominant kernel of the last
  * mfx_fit_batch*_ call on this thread, measured with hipEvents on the launch stream
  * (valid after the stream has been synchronised); < 0 if unavailable.              */

@@ -21,7 +21,7 @@ EXPORTS = [
     "mfx_tables_create", "mfx_tables_destroy", "mfx_tables_num_atoms",
     "mfx_plan_create_multishell", "mfx_plan_create_explicit", "mfx_plan_destroy",
     "mfx_rotate", "mfx_rotate_dev", "mfx_rotate_cols", "mfx_rotate_cols_dev", "mfx_fit_batch", "mfx_fit_batch_dev",
-    "mfx_solve_exhaustive", "mfx_last_kernel_ms", "mfx_set_profiling", "mfx_debug_set_stamps",
+    "mfx_solve_exhaustive", "mfx_monte_carlo_average", "mfx_monte_carlo_average_dev", "mfx_last_kernel_ms", "mfx_set_profiling", "mfx_debug_set_stamps",
 ]
 
 
@@ -61,6 +61,9 @@ def lib():
     L.mfx_fit_batch.argtypes = [vp, dp, ip, bp, bp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int64, dp]
     L.mfx_fit_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp]
     L.mfx_solve_exhaustive.argtypes = [dp, C.c_int64, C.c_int, lp, C.c_int, dp, dp, lp, lp, dp, dp]
+    L.mfx_monte_carlo_average.argtypes = [dp, C.c_int64, C.c_int, lp, dp, C.c_double, C.c_int64, C.c_int64, dp, C.c_int]
+    L.mfx_monte_carlo_average_dev.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, lp, dp, C.c_double, C.c_int64,
+                                              C.c_int64, dp, vp]
     L.mfx_last_kernel_ms.restype = C.c_double
     L.mfx_set_profiling.argtypes = [C.c_int]
     L.mfx_set_profiling.restype = None

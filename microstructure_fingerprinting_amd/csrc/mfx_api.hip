@@ -19,6 +19,7 @@
 #include "fit_k2x.hip"
 #include "rotate.hip"
 #include "solve_generic.hip"
+#include "mc_average.hip"
 #include "mfx_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -619,4 +620,100 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
   for (int k = 0; k < Kp; ++k) { sub[k] = hsub[k]; tot[k] = a.start[k] + hsub[k]; }
   cleanup();
   return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Monte-Carlo signal synthesis from spin phases (mf_utils.py:2758-2810)
+namespace {
+struct DevMem {   // frees on scope exit
+  void* p = nullptr;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <class T> T* as() const { return (T*)p; }
+};
+}  // namespace
+
+extern "C" int mfx_monte_carlo_average_dev(const double* d_phases, int64_t n_entries, int64_t spin_stride,
+                                           int64_t dim_stride, int dim, const int64_t* delta_mapping,
+                                           const double* gscaling, double Dscaling, int64_t num_spins, int64_t n_seq,
+                                           double* signal, void* stream) {
+  if (n_seq < 0 || dim < 1 || dim > 3 || num_spins < 1 || n_entries < 0)
+    return fail(MFX_ERR_ARG, "mfx_monte_carlo_average: need n_seq >= 0, 1 <= dim <= 3, num_spins >= 1");
+  if (n_seq == 0) return MFX_OK;
+  if (!d_phases || !delta_mapping || !gscaling || !signal) return fail(MFX_ERR_ARG, "mfx_monte_carlo_average: null argument");
+  if (n_seq > (1 << 24)) return fail(MFX_ERR_UNSUPPORTED, "mfx_monte_carlo_average: more than 2^24 sequences");
+  const int64_t n_ref = n_entries / num_spins;
+  for (int64_t i = 0; i < n_seq; ++i)
+    if (delta_mapping[i] < 0 || delta_mapping[i] >= n_ref)
+      return fail(MFX_ERR_ARG, "delta_mapping[%lld] = %lld outside the %lld simulated acquisitions of the phase table",
+                  (long long)i, (long long)delta_mapping[i], (long long)n_ref);
+  hipStream_t st = (hipStream_t)stream;
+  // group the sequences by simulated acquisition (stable), cut the groups into tiles of MFX_MC_TS
+  std::vector<int> order((size_t)n_seq);
+  for (int64_t i = 0; i < n_seq; ++i) order[(size_t)i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return delta_mapping[x] < delta_mapping[y]; });
+  std::vector<int> t_first, t_cnt;
+  std::vector<long> t_start;
+  std::vector<double> gs((size_t)n_seq * 3, 0.0);
+  for (int64_t q = 0; q < n_seq; ++q) {
+    const int i = order[(size_t)q];
+    for (int d = 0; d < dim; ++d) gs[(size_t)q * 3 + d] = gscaling[(size_t)i * dim + d];
+    const int64_t ref = delta_mapping[i];
+    if (q == 0 || delta_mapping[order[(size_t)q - 1]] != ref || t_cnt.back() == MFX_MC_TS) {
+      t_first.push_back((int)q); t_cnt.push_back(0); t_start.push_back((long)(ref * num_spins));
+    }
+    ++t_cnt.back();
+  }
+  const int64_t nchunks64 = (num_spins + MFX_MC_CHUNK - 1) / MFX_MC_CHUNK;
+  const int64_t nblocks = nchunks64 * (int64_t)t_first.size();
+  if (nchunks64 > (1 << 30) || nblocks >= (1LL << 31)) return fail(MFX_ERR_UNSUPPORTED, "mfx_monte_carlo_average: launch too large");
+  McArgs a{};
+  a.ph = d_phases; a.spin_stride = spin_stride; a.dim_stride = dim_stride; a.dim = dim; a.Ds = Dscaling;
+  a.num_spins = num_spins; a.n_tiles = (int)t_first.size(); a.nchunks = (int)nchunks64; a.n_seq = (int)n_seq;
+  DevMem dfirst, dcnt, dstart, dgs, dord, dpart, dsig;
+  HIPCHK(dfirst.alloc(sizeof(int) * t_first.size()));
+  HIPCHK(dcnt.alloc(sizeof(int) * t_cnt.size()));
+  HIPCHK(dstart.alloc(sizeof(long) * t_start.size()));
+  HIPCHK(dgs.alloc(sizeof(double) * gs.size()));
+  HIPCHK(dord.alloc(sizeof(int) * order.size()));
+  HIPCHK(dpart.alloc(sizeof(double) * (size_t)n_seq * a.nchunks));
+  HIPCHK(dsig.alloc(sizeof(double) * (size_t)n_seq));
+  HIPCHK(hipMemcpyAsync(dfirst.p, t_first.data(), sizeof(int) * t_first.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dcnt.p, t_cnt.data(), sizeof(int) * t_cnt.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dstart.p, t_start.data(), sizeof(long) * t_start.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dgs.p, gs.data(), sizeof(double) * gs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dord.p, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
+  a.tile_first = dfirst.as<int>(); a.tile_cnt = dcnt.as<int>(); a.tile_start = dstart.as<long>();
+  a.gs = dgs.as<double>(); a.order = dord.as<int>(); a.partial = dpart.as<double>(); a.signal = dsig.as<double>();
+  if (g_profiling) {
+    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
+    HIPCHK(hipEventRecord(g_ev0, st));
+  }
+  hipLaunchKernelGGL(mfx_mc_partial_kernel, dim3((unsigned)nblocks), dim3(MFX_MC_THREADS), 0, st, a);
+  HIPCHK(hipGetLastError());
+  if (g_profiling) {
+    HIPCHK(hipEventRecord(g_ev1, st));
+    g_ev_launches = 1;
+    g_ev_valid = true;
+  }
+  hipLaunchKernelGGL(mfx_mc_finalize_kernel, dim3((unsigned)n_seq), dim3(64), 0, st, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(signal, dsig.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));      // temporaries are released on return
+  return MFX_OK;
+}
+
+extern "C" int mfx_monte_carlo_average(const double* sim_phases, int64_t n_entries, int dim, const int64_t* delta_mapping,
+                                       const double* gscaling, double Dscaling, int64_t num_spins, int64_t n_seq,
+                                       double* signal, int device) {
+  if (n_seq < 0 || dim < 1 || dim > 3 || num_spins < 1 || n_entries < 0)
+    return fail(MFX_ERR_ARG, "mfx_monte_carlo_average: need n_seq >= 0, 1 <= dim <= 3, num_spins >= 1");
+  if (n_seq == 0) return MFX_OK;
+  if (!sim_phases) return fail(MFX_ERR_ARG, "mfx_monte_carlo_average: null argument");
+  if (int rc = require_device(device)) return rc;
+  DevMem dph;
+  HIPCHK(dph.alloc(sizeof(double) * (size_t)n_entries * dim));
+  HIPCHK(hipMemcpy(dph.p, sim_phases, sizeof(double) * (size_t)n_entries * dim, hipMemcpyHostToDevice));
+  return mfx_monte_carlo_average_dev(dph.as<double>(), n_entries, dim, 1, dim, delta_mapping, gscaling, Dscaling, num_spins,
+                                     n_seq, signal, nullptr);
 }

@@ -14,6 +14,10 @@ interp_PGSE_from_multishell (ref:1693)         checks on host, evaluation on dev
 rotate_atom (ref:1205)                         per-shell knot tables on host, evaluation on device
 import_PGSE_scheme (ref:2128)                  host (input normalisation, once per fit)
 get_PGSE_scheme_from_bval_bvec_dense (2197)    host
+monte_carlo_average (ref:2762)                 device (mfx_monte_carlo_average)
+get_PGSE_from_phases (ref:2813)                file parsing / (Delta, delta) mapping on host, phase planes
+                                               uploaded once, cosine reduction on device
+DT_* / peaks_to_DT_vec (ref:865-1135)          host (orientation input normalisation)
 loadmat (ref:3026)                             host (SciPy)
 =============================================  ================================================
 
@@ -520,6 +524,118 @@ def peaks_to_DT_vec(peaks, order, lam_par=2e-3, lam_perp=0.1e-3):
     tens = np.zeros(peaks.shape[:-1] + (6,))
     tens[nz, :] = np.stack([DT[:, r, c] for (r, c) in pos], axis=-1)
     return [tens[..., k, :] for k in range(peaks.shape[-2])]
+
+
+# ---------------------------------------------------------------------------------------------
+# Monte-Carlo signal synthesis from stored spin phases (dictionary generation)
+# ---------------------------------------------------------------------------------------------
+def monte_carlo_average(sim_phases, delta_mapping, gscaling, Dscaling, num_spins, device=0):
+    """``S_i = mean_l cos(Dscaling * sum_n gscaling[i,n] * sim_phases[delta_mapping[i]*num_spins + l, n])``
+    (ref:2758-2810), evaluated on the GPU.  Per-term arithmetic follows the reference order; the
+    spins are summed in a fixed tree order instead of sequentially."""
+    ph = L.f64c(sim_phases)
+    if ph.ndim != 2:
+        raise ValueError("sim_phases should have 2 dimensions (n_spin*n_ref, n_dim), detected %d." % ph.ndim)
+    dm = np.ascontiguousarray(delta_mapping, dtype=np.int64).reshape(-1)
+    gs = L.f64c(gscaling)
+    if gs.ndim != 2 or gs.shape[0] != dm.size or gs.shape[1] != ph.shape[1]:
+        raise ValueError("gscaling should have shape (%d, %d), got %s." % (dm.size, ph.shape[1], gs.shape))
+    out = np.zeros(dm.size)
+    L.check(L.lib().mfx_monte_carlo_average(L.dptr(ph), ph.shape[0], ph.shape[1], L.lptr(dm), L.dptr(gs),
+                                            float(Dscaling), int(num_spins), dm.size, L.dptr(out), int(device)))
+    return out
+
+
+def _phase_file_format(phasefile):
+    """('<'|'>', 'f4'|'f8', bytes per item, directory, basename, extension) from the file name
+    (ref:2904-2934): extension = endianness letter (b/l) + storage type (single|float|double)."""
+    import os
+    folder, tail = os.path.split(phasefile)
+    base, ext = os.path.splitext(tail)
+    if not ext:
+        raise ValueError("Phase file extension not found.\nAborting as there is no way to tell which level of "
+                         "precision was used to store the phase values (e.g., float, double, ...).")
+    endian = {'b': '>', 'l': '<'}.get(ext[1].lower())
+    if endian is None:
+        raise ValueError("Phase file extension (after the dot) should start with a b for big endian or with a l "
+                         "for little endian. Detected: \"%s\"." % ext[1])
+    if ext[2:] in ('single', 'float'):
+        kind, width = 'f4', 4
+    elif ext[2:] == 'double':
+        kind, width = 'f8', 8
+    else:
+        raise ValueError("Data type of phase file specified in file extension (\"%s\") not supported." % ext[2:])
+    return endian, kind, width, folder, base, ext
+
+
+def get_PGSE_from_phases(phasefile, sch_mat_sim, sch_mat, dim=None, D_sim=None, D=None, device=0):
+    """PGSE signal for protocol ``sch_mat`` from the spins' phases of a reference Monte-Carlo run
+    (ref:2813-3015; same arguments, checks and messages).  The phase files (one per gradient
+    component, ``*_phase_x|y|z.<b|l><single|float|double>``) are staged to HBM as one plane per
+    component -- no host-side interleaving -- and reduced there."""
+    import os
+    import torch
+    names = ['x', 'y', 'z']
+    MAXDIM = 3
+    D_ratio_sqrt = 1.0
+    if D is not None:
+        if D_sim is None:
+            raise NameError("Simulation diffusivity should be specified if new signal diffusivity is set.")
+        D_ratio_sqrt = float(np.sqrt(D / D_sim))
+    if dim is None:
+        dim = MAXDIM
+    elif dim > MAXDIM:
+        raise ValueError("dim should be less than or equal to %d." % MAXDIM)
+    sch_sim = import_PGSE_scheme(sch_mat_sim)
+    sch = import_PGSE_scheme(sch_mat)
+    if np.any(sch[:, dim:MAXDIM] != 0):
+        print("WARNING get_PGSE_from_phases: detected non-zero entries in gradient components after dimension %d.\n"
+              "Those components will be ignored but make sure the right acquisition protocol was provided.\n"
+              "It is common for such protocols to contain zeros in those gradient components, for instance after "
+              "projection into the xy-plane of a 3D protocol.\n" % dim)
+    num_seq, num_ref = sch.shape[0], sch_sim.shape[0]
+    g_sim = sch_sim[:, :3] * sch_sim[:, 3][:, np.newaxis]
+    g_new = sch[:, :3] * sch[:, 3][:, np.newaxis]
+    # each new sequence -> LAST simulated sequence with the same (Delta, delta) (ref:2874-2880)
+    delta_mapping = np.full(num_seq, -1, dtype=np.int64)
+    for i in range(num_ref):
+        delta_mapping[np.all(sch[:, 4:6] == sch_sim[i, 4:6], axis=1)] = i
+    bad = np.where(delta_mapping < 0)[0]
+    if bad.size > 0:
+        listing = '\n'.join('\t%4d -- %5g -- %5g' % (b, sch[b, 4] * 1e3, sch[b, 5] * 1e3) for b in bad)
+        raise ValueError('Acquisition protocol contains %d (Delta,delta) pair(s) (out of %d) not used to simulate the '
+                         'directional phases in the Monte Carlo simulation. List of unmatched sequences:\nSequ. no. '
+                         '-- Delta [ms] -- delta [ms]\n%s' % (bad.size, num_seq, listing))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        gscaling = np.ascontiguousarray(g_new[:, :dim] / g_sim[delta_mapping, :dim])
+    if not os.path.isfile(phasefile):
+        raise RuntimeError("File %s does not exist." % phasefile)
+    nbytes = os.path.getsize(phasefile)
+    endian, kind, width, folder, base, ext = _phase_file_format(phasefile)
+    if nbytes % (num_ref * width) != 0:
+        raise RuntimeError("Phase file %s is either corrupted or inconsistently named. Storage precision of items "
+                           "(%d bytes) times number of reference simulation sequences (%d) does not divide total "
+                           "size (%d bytes)." % (phasefile, width, num_ref, nbytes))
+    num_entries = nbytes // width
+    num_spins = num_entries // num_ref
+    lib = L.lib()
+    if lib.mfx_device_count() <= 0:
+        raise L.MfxError("no HIP device available (this library has no CPU path)")
+    dev = torch.device("cuda", int(device))
+    planes = torch.empty((dim, num_entries), dtype=torch.float64, device=dev)     # one plane per component
+    for i in range(dim):
+        f_i = os.path.join(folder, base[:-len(names[i])] + names[i] + ext)
+        if not os.path.isfile(f_i):
+            raise RuntimeError("Phase file %s not found." % f_i)
+        raw = np.fromfile(f_i, dtype=endian + kind, count=num_entries, sep="")
+        planes[i].copy_(torch.from_numpy(raw.astype(np.float64)))
+    out = np.zeros(num_seq)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev)
+        L.check(lib.mfx_monte_carlo_average_dev(planes.data_ptr(), num_entries, 1, num_entries, dim, L.lptr(delta_mapping),
+                                                L.dptr(gscaling), D_ratio_sqrt, num_spins, num_seq, L.dptr(out),
+                                                st.cuda_stream))
+    return out
 
 
 def loadmat(filename):

@@ -617,6 +617,32 @@ int orc_fit_batch(int S, int N, const double* G_un, const int* off, const double
   return err;
 }
 
+/* ---------------------------------------------------------------------------
+ * Monte-Carlo average of the spins' dephasing: mfu:2762-2810, loop for loop
+ * (sequential sum over spins, products accumulated in dimension order, libm cos).
+ * nthreads > 1 splits the SEQUENCES (independent outputs) over OpenMP threads.   */
+int orc_monte_carlo_average(const double* sim_phases, long n_entries, int dim, const long* delta_mapping,
+                            const double* gscaling, double Dscaling, long num_spins, long n_seq, double* signal,
+                            int nthreads) {
+  for (long i = 0; i < n_seq; ++i)
+    if (delta_mapping[i] < 0 || (delta_mapping[i] + 1) * num_spins > n_entries) return 2;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (long iseq = 0; iseq < n_seq; ++iseq) {
+    const long start = delta_mapping[iseq] * num_spins;      /* mfu:2801-2802 */
+    double acc = 0.0;
+    for (long ispin = 0; ispin < num_spins; ++ispin) {
+      double ph_final = 0.0;                                 /* mfu:2804 */
+      const double* p = sim_phases + (start + ispin) * dim;
+      for (int idim = 0; idim < dim; ++idim) ph_final += gscaling[iseq * dim + idim] * p[idim];   /* mfu:2806-2807 */
+      acc += cos(Dscaling * ph_final);                       /* mfu:2808 */
+    }
+    signal[iseq] = acc / (double)num_spins;                  /* mfu:2809 */
+  }
+  return 0;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -52,6 +52,9 @@ def lib():
                                        C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), dp, C.c_int, C.c_int, C.c_int,
                                        dp, dp, C.c_int, C.c_long, dp, C.c_int]
         _LIB.orc_fit_batch.restype = C.c_int
+        _LIB.orc_monte_carlo_average.argtypes = [dp, C.c_long, C.c_int, lp, dp, C.c_double, C.c_long, C.c_long, dp,
+                                                 C.c_int]
+        _LIB.orc_monte_carlo_average.restype = C.c_int
         _LIB.orc_max_threads.restype = C.c_int
     return _LIB
 
@@ -262,6 +265,20 @@ def fit_batch(T, sch_mat, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_cs
         raise ValueError("Gradient intensity outside the multi-shell range; extrapolation not supported.")
     if rc:
         raise RuntimeError("oracle fit error %d" % rc)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Monte-Carlo signal synthesis: mfu:2758-2810
+def monte_carlo_average(sim_phases, delta_mapping, gscaling, Dscaling, num_spins, nthreads=1):
+    ph = np.ascontiguousarray(sim_phases, dtype=np.float64)
+    dm = np.ascontiguousarray(delta_mapping, dtype=np.int64)
+    gs = np.ascontiguousarray(gscaling, dtype=np.float64)
+    out = np.zeros(dm.size)
+    rc = lib().orc_monte_carlo_average(_dp(ph), ph.shape[0], ph.shape[1], _lp(dm), _dp(gs), float(Dscaling),
+                                       int(num_spins), dm.size, _dp(out), int(nthreads))
+    if rc:
+        raise IndexError("delta_mapping points outside the phase table")
     return out
 
 

@@ -457,6 +457,52 @@ def gen_cleanup(mfu, mfmod):
     print("cleanup_cases.npz written; num_fasc histogram", np.bincount(out["peaks_nf"].astype(int).ravel()))
 
 
+def gen_mc(mfu):
+    """monte_carlo_average (mfu:2758-2810) and get_PGSE_from_phases (mfu:2813-3015) on a small synthetic
+    phase table: 3 simulated (Delta, delta) acquisitions x 700 spins x 3 components."""
+    rng = np.random.default_rng(4242)
+    n_ref, n_spin = 3, 700
+    Dl = np.array([20e-3, 35e-3, 50e-3]); dl = np.array([8e-3, 10e-3, 12e-3])
+    Gsim = 0.05
+    sch_sim = np.zeros((n_ref, 7))
+    sch_sim[:, :3] = 1 / np.sqrt(3.0)
+    sch_sim[:, 3], sch_sim[:, 4], sch_sim[:, 5], sch_sim[:, 6] = Gsim, Dl, dl, Dl + dl + 5e-3
+    # phases ~ gamma*G*delta*displacement, a few rad; heavier tails on one component
+    ph = rng.standard_normal((n_ref * n_spin, 3)) * np.array([1.5, 1.0, 4.0])
+    out = {"sch_sim": sch_sim, "phases": ph, "n_spin": np.int64(n_spin)}
+    # direct kernel call
+    n_seq = 23
+    dm = rng.integers(0, n_ref, n_seq).astype(np.int64)
+    gs = rng.uniform(-2, 2, (n_seq, 3))
+    gs[0] = 0.0
+    out["dm"], out["gs"] = dm, gs
+    out["sig_direct"] = mfu.monte_carlo_average(ph, dm, gs, 1.0, n_spin)
+    out["sig_direct_D"] = mfu.monte_carlo_average(ph, dm, gs, float(np.sqrt(2.0e-9 / 3.0e-9)), n_spin)
+    out["sig_dim2"] = mfu.monte_carlo_average(np.ascontiguousarray(ph[:, :2]), dm, np.ascontiguousarray(gs[:, :2]), 1.0, n_spin)
+    # through phase files: big-endian double and little-endian float
+    sch = np.zeros((17, 7))
+    g = unit(rng, 17)
+    sch[:, :3] = g
+    pick = rng.integers(0, n_ref, 17)
+    sch[:, 3] = rng.uniform(0.0, 0.08, 17)
+    sch[:, 4], sch[:, 5], sch[:, 6] = Dl[pick], dl[pick], (Dl + dl)[pick] + 5e-3
+    sch[3, :4] = 0.0      # a b0
+    out["sch_new"] = sch
+    d = tempfile.mkdtemp(prefix="mcphases_")
+    for i, nm in enumerate("xyz"):
+        ph[:, i].astype(">f8").tofile(os.path.join(d, "sim_phase_%s.bdouble" % nm))
+        ph[:, i].astype("<f4").tofile(os.path.join(d, "sim_phase_%s.lfloat" % nm))
+    out["sig_files_bdouble"] = mfu.get_PGSE_from_phases(os.path.join(d, "sim_phase_x.bdouble"), sch_sim, sch)
+    out["sig_files_lfloat_D"] = mfu.get_PGSE_from_phases(os.path.join(d, "sim_phase_x.lfloat"), sch_sim, sch,
+                                                          D_sim=3.0e-9, D=2.0e-9)
+    sch2 = sch.copy(); sch2[:, 2] = 0
+    n2 = np.linalg.norm(sch2[:, :3], axis=1); sch2[n2 > 0, :3] /= n2[n2 > 0][:, None]
+    out["sch_new_xy"] = sch2
+    out["sig_files_dim2"] = mfu.get_PGSE_from_phases(os.path.join(d, "sim_phase_x.bdouble"), sch_sim, sch2, dim=2)
+    np.savez_compressed(os.path.join(OUT, "mc_cases.npz"), **out)
+    print("mc_cases.npz written", out["sig_direct"][:4], out["sig_files_bdouble"][:4])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -464,7 +510,8 @@ if __name__ == "__main__":
     mfu, mfmod = import_reference()
     todo = {"solver": lambda: gen_solver(mfu), "rotation": lambda: gen_rotation(mfu),
             "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod),
-            "inputs": lambda: gen_inputs(mfu, mfmod), "cleanup": lambda: gen_cleanup(mfu, mfmod)}
+            "inputs": lambda: gen_inputs(mfu, mfmod), "cleanup": lambda: gen_cleanup(mfu, mfmod),
+            "mc": lambda: gen_mc(mfu)}
     for k, fn in todo.items():
         if a.only in (None, k):
             fn()
