@@ -131,6 +131,11 @@ void mfx_set_profiling(int enabled);
 /* Diagnostic builds only (-DMFX_STAMPS): device buffer [grid x 16] of s_memtime stamps written by the
  * K=2 kernel at its phase boundaries; a no-op in the shipped build.                                */
 void mfx_debug_set_stamps(void* dev_ptr);
+/* Diagnostic: number of two-fascicle voxels of the last mfx_fit_batch*_ class launch on this thread that the
+ * split-FP16 screening kernel handed back to the FP64 kernel (short-list overflow); 0 in the normal case. */
+int mfx_debug_last_fallback_count(void);
+/* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
+void mfx_debug_set_k2_screen(int enabled);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,8 @@ struct FitK2Args {
   int maxfasc;
   int csf_on, ear_on;
   unsigned long long* stamps;  // diagnostic builds only: [gridDim.x][16] s_memtime stamps (null otherwise)
+  int* fb_count;        // screening kernel (fit_k2s.hip) only: number of voxels handed back to the FP64 kernel ...
+  int* fb_list;         // ... and their voxel indices
 };
 
 #ifdef MFX_STAMPS

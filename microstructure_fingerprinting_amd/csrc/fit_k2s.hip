@@ -1,0 +1,467 @@
+// fit_k2s.hip -- two-fascicle voxels, exact-G protocols: split-FP16 MFMA SCREENING of all atom pairs
+// followed by the exact FP64 evaluation of the short list.  Same inputs, outputs and results as
+// mfx_fit_k2_kernel (fit_k2.hip), which stays the path for G-bracketed / long protocols and the
+// fallback for the rare voxel whose short list overflows.
+//
+// Why: the 2*N1*N2*M cross-Gram of solve_exhaustive_posweights_2 (mf_utils.py:307-325) only RANKS the
+// pairs; the reference's answer is decided by the few pairs within rounding distance of the best one.
+// So the Gram is computed here from operands split into two FP16 halves,
+//        a = hi + 2^-11 lo (+ r),  |r| <= 1.25 * 2^-22 |a|,      c~ = hi.hi + 2^-11 (hi.lo + lo.hi)
+// on v_mfma_f32_32x32x16_f16 (3 instructions per 32x32x16 block, 32x the FP64 MFMA rate), with unit-norm
+// columns so that c~ is the cosine of the pair up to |c~ - c| <= DC (DC = 1e-5 is >10x the measured
+// maximum, bound: 3.5 * 2^-22 truncation + FP32 accumulation of 13 MFMA steps over sum|a_i b_i| <= 1).
+// For a pair whose optimum has two positive weights the score S = |y|^2 - residual obeys dS/dc = -2 w1 w2
+// with w1 w2 <= |y|^2 / 2 (c >= 0), so |S(c~) - S(c)| <= DC |y|^2 =: m.  Every pair with S(c~) >= thr is
+// appended to a ring in LDS, thr = (largest S(c~) seen) - 2m, which can only drop pairs that are not the
+// optimum; nearly collinear pairs (1 - c~^2 < 1e-3), where S(c) is ill-conditioned, go through an
+// interval upper bound instead.  The survivors (typically < 20 of 611 524) are evaluated by the same
+// exact stage as in fit_k2.hip (reference arithmetic and order, strict-'<' first hit, family expansion).
+// A ring entry that is overwritten while it could still matter raises a flag and the voxel is redone
+// by the FP64 kernel (host side, mfx_api.hip), so the result never depends on the ring size.
+//
+// Structure: one 512-thread workgroup per voxel, 8 waves = 8 row tiles of 32 atoms of D1 per round; a
+// wave keeps its tile (hi and lo, K = 16*KS) in 8*KS VGPRs; D2 is generated 32 atoms at a time into a
+// double-buffered LDS image laid out in MFMA fragment order (ds_read_b128, conflict-free).
+#pragma once
+#include "fit_k2.hip"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFX_S_CAP 1024      // ring entries (power of two)
+#define MFX_S_DC 1e-5       // bound on |c~ - c|
+#define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
+
+// bit pattern of max(x, +0): non-negative doubles order like unsigned integers (LDS atomicMax)
+__device__ __forceinline__ unsigned long long mfx_nonneg_bits(double x) {
+  return (unsigned long long)__double_as_longlong(x > 0.0 ? x : 0.0);
+}
+
+__device__ __forceinline__ void mfx_split16(double v, _Float16& hi, _Float16& lo) {
+  const float f = (float)v;
+  hi = (_Float16)f;
+  lo = (_Float16)((f - (float)hi) * 2048.0f);
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
+  constexpr int WG = 512, NW = 8;
+  constexpr int MP = KS * 16;  // padded measurement count
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int M = a.P.M, N = a.T.N, ldn = a.T.ldn;
+  const int NP = (N + 31) & ~31;  // atoms padded to a multiple of 32
+  const int ntiles = NP >> 5;
+  const double2* __restrict__ tab = a.T.tab;
+  const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
+
+  // ---- LDS carve-up
+  _Float16* sBh = (_Float16*)smem;                 // [2][KS][64][8]  hi halves, fragment order
+  _Float16* sBl = sBh + 2 * KS * 512;              // [2][KS][64][8]  lo halves
+  double* s_y = (double*)(sBl + 2 * KS * 512);     // [MP]
+  double* s_t0 = s_y + MP;                         // [2][MP]
+  double* s_I1 = s_t0 + 2 * MP;                    // [NP] 1/|d1|   (0 beyond N)
+  double* s_Z1 = s_I1 + NP;                        // [NP] d1.y/|d1| (-inf beyond N)
+  double* s_I2 = s_Z1 + NP;
+  double* s_Z2 = s_I2 + NP;
+  double* s_red = s_Z2 + NP;                       // [32] scratch
+  Cand* s_cand = (Cand*)(s_red + 32);              // [MFX_S_CAP]
+  unsigned long long* s_thr = (unsigned long long*)(s_cand + MFX_S_CAP);  // [0] threshold bits, [1] lost-entry max bits
+  int* s_r0 = (int*)(s_thr + 2);                   // [2][MP] knot row * ldn (element offset of the row in the table)
+  int* s_cnt = s_r0 + 2 * MP;                      // [4]
+
+  MFX_STAMP(0);
+  // ---- phase 0: y, knot-interval descriptors
+  const double* __restrict__ yv = a.Y + (size_t)vox * M;
+  const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
+  for (int m = tid; m < MP; m += WG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int idx = tid; idx < 2 * MP; idx += WG) {
+    const int k = idx / MP, m = idx - k * MP;
+    RowDesc rd;
+    rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;  // padded rows -> the all-zero table row
+    if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
+    s_r0[idx] = rd.r0 * ldn;
+    s_t0[idx] = rd.t0;
+  }
+  if (tid == 0) { s_cnt[0] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  __syncthreads();
+
+  // table entry (row offset ro, atom n) through a 32-bit element offset: SGPR base + VGPR offset addressing
+  auto tab_at = [&](int ro, int n) -> double2 { return *(const double2*)((const char*)tab + ((unsigned)(ro + n) << 4)); };
+  // exact-arithmetic rotated dictionary entry: slope * t + y_lo, separate mul and add (mfx_eval)
+  auto elem = [&](int k, int m, int n) -> double {
+    const double2 e = tab_at(s_r0[k * MP + m], n);
+    return e.y * s_t0[k * MP + m] + e.x;
+  };
+
+  MFX_STAMP(1);
+  // ---- phase 1: column statistics; y_sq sequential as mf_utils.py:307-325
+  double y_sq = 0.0;
+  for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
+  const double mrg = MFX_S_DC * y_sq;        // |S(c~) - S(c)| <= mrg
+  const double etol = MFX_S_DC * sqrt(y_sq); // |e(c~) - e(c)| <= etol
+  double my_s[2] = {0.0, 0.0};
+  int my_n[2] = {0, 0};
+  for (int col = tid; col < 2 * NP; col += WG) {
+    const int k = col >= NP, n = col - k * NP;
+    double a2 = 0.0, ay = 0.0;
+    if (n < N) {
+#pragma unroll 8
+      for (int m = 0; m < M; ++m) {  // ranking statistics only (the exact stage re-sums in reference order)
+        const double2 e = tab_at(s_r0[k * MP + m], n);
+        const double d = fma(e.y, s_t0[k * MP + m], e.x);
+        a2 = fma(d, d, a2);
+        ay = fma(s_y[m], d, ay);
+      }
+    }
+    const double inv = (n < N && a2 > 0.0) ? 1.0 / sqrt(a2) : 0.0;
+    const double z = ay * inv;
+    (k ? s_I2 : s_I1)[n] = inv;
+    (k ? s_Z2 : s_Z1)[n] = (n < N) ? z : -INFINITY;
+    const double s = z > 0.0 ? z * z : 0.0;
+    if (n < N && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }
+  }
+  // best single atom of each dictionary (first index on ties): they stand for every pair whose optimum
+  // has one active atom (mf_utils.py:357-379); the exact stage expands the winner's family
+  {
+    double* s_bs = s_red;            // [2][8]
+    int* s_bn = (int*)(s_red + 16);  // [2][8]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double s = my_s[k];
+      int n = my_n[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double s2 = __shfl_xor(s, o);
+        const int n2 = __shfl_xor(n, o);
+        const bool take = (s2 > s) || (s2 == s && n2 < n);
+        s = take ? s2 : s;
+        n = take ? n2 : n;
+      }
+      if (lane == 0) { s_bs[k * 8 + wave] = s; s_bn[k * 8 + wave] = n; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double best1 = 0.0;
+      for (int k = 0; k < 2; ++k) {
+        double s = s_bs[k * 8];
+        int n = s_bn[k * 8];
+        for (int w = 1; w < 8; ++w) {
+          const double s2 = s_bs[k * 8 + w];
+          const int n2 = s_bn[k * 8 + w];
+          if (s2 > s || (s2 == s && n2 < n)) { s = s2; n = n2; }
+        }
+        best1 = fmax(best1, s);
+        if (s > 0.0) {
+          const int slot = s_cnt[0]++;
+          s_cand[slot].score = INFINITY;  // always evaluated
+          s_cand[slot].i = k ? 0 : n;
+          s_cand[slot].j = k ? n : 0;
+        }
+      }
+      // single-atom scores are exact: a pair matters only if S(c) >= best1, i.e. S(c~) >= best1 - mrg
+      s_thr[0] = mfx_nonneg_bits(best1 - mrg);
+    }
+  }
+  __syncthreads();
+
+  // generation of one 32-atom chunk of normalised D2 as FP16 hi/lo fragments: item = (atom c, 4 consecutive rows)
+  auto gen_chunk = [&](int ch, int buf) {
+    for (int item = tid; item < 32 * 4 * KS; item += WG) {
+      const int c = item & 31, q = item >> 5;
+      const int n = ch * 32 + c;
+      const double sc = s_I2[n];
+      const int nn = min(n, ldn - 1);
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = 4 * q + e;
+        const double2 d = tab_at(s_r0[MP + m], nn);
+        _Float16 x, y;
+        mfx_split16(fma(d.y, s_t0[MP + m], d.x) * sc, x, y);
+        hi[e] = x; lo[e] = y;
+      }
+      const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
+      *(h4*)(sBh + buf * KS * 512 + off) = hi;
+      *(h4*)(sBl + buf * KS * 512 + off) = lo;
+    }
+  };
+
+  // ring append (rare path)
+  auto push = [&](double S, int i, int j) {
+    const int slot = atomicAdd(&s_cnt[0], 1);
+    const int idx = slot & (MFX_S_CAP - 1);
+    if (slot >= MFX_S_CAP) {   // overwriting: remember the best score that got lost
+      const double old = s_cand[idx].score;
+      atomicMax(&s_thr[1], mfx_nonneg_bits(fmin(old, 1e300)));
+    }
+    s_cand[idx].score = S;
+    s_cand[idx].i = i;
+    s_cand[idx].j = j;
+  };
+
+  MFX_STAMP(2);
+  const int nrounds = (ntiles + NW - 1) / NW;
+  for (int round = 0; round < nrounds; ++round) {
+    const int rt = round * NW + wave;
+    const bool rt_valid = rt < ntiles;  // wave-uniform
+    const int rtc = rt_valid ? rt : 0;
+    // A operand: this wave's 32 atoms of D1 (normalised, split), all KS k-steps, in registers
+    h8 afh[KS], afl[KS];
+    {
+      const int n = rtc * 32 + lr;
+      const double asc = rt_valid ? s_I1[n] : 0.0;
+      const int nn = min(n, ldn - 1);
+      mfx_static_for<0, KS>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        double2 d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = tab_at(s_r0[16 * ks + 8 * lh + j], nn);
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 x, y;
+          mfx_split16(fma(d[j].y, s_t0[16 * ks + 8 * lh + j], d[j].x) * asc, x, y);
+          vh[j] = x; vl[j] = y;
+        }
+        asm volatile("" : "+v"(vh), "+v"(vl));   // materialise here: the conversions must not sink below all loads
+        afh[ks] = vh; afl[ks] = vl;
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    double z1r[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) z1r[g] = s_Z1[rtc * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh];
+
+    if (round == 0) MFX_STAMP(3);
+    gen_chunk(0, 0);
+    __syncthreads();
+    if (round == 0) MFX_STAMP(4);
+    double thr = __longlong_as_double((long long)s_thr[0]);
+
+    for (int ch = 0; ch < ntiles; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+      if (rt_valid) {
+        f32x16 acc_h, acc_x;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+        const _Float16* bhp = sBh + buf * KS * 512 + lane * 8;
+        const _Float16* blp = sBl + buf * KS * 512 + lane * 8;
+        h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
+        mfx_static_for<0, KS>([&](auto kc) {
+          constexpr int ks = decltype(kc)::value;
+          h8 bhn = bh, bln = bl;
+          if constexpr (ks + 1 < KS) {   // fragments of the next k-step while this one multiplies
+            bhn = *(const h8*)(bhp + (ks + 1) * 512);
+            bln = *(const h8*)(blp + (ks + 1) * 512);
+          }
+          acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc_h, 0, 0, 0);
+          acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc_x, 0, 0, 0);
+          acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc_x, 0, 0, 0);
+          bh = bhn; bl = bln;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr
+        thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
+        const int j = ch * 32 + lr;
+        const double z2 = s_Z2[j];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
+          const double z1 = z1r[g];
+          const double e1 = fma(-c, z2, z1);
+          const double e2 = fma(-c, z1, z2);
+          const double den = fma(-c, c, 1.0);
+          const double num = fma(z2, e2, z1 * e1);
+          const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
+          const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
+          const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
+          const bool near = pos & !wellc;
+          if (__any(hit | near)) {   // wave-uniform, rare once thr is close to the optimum
+            double S = -1.0;
+            if (hit) {
+              S = num / den;
+            } else if (near) {
+              // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
+              // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
+              const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
+              const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
+              S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
+            }
+            // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not a
+            // score and never raises it), then append only what still reaches it: no burst of stale entries
+            const double smax = wave_max(hit ? S : 0.0);
+            if (smax - 2.0 * mrg > thr) {
+              thr = smax - 2.0 * mrg;
+              if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
+            }
+            if ((hit | near) && S >= thr) push(S, rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh, j);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (round == 0) MFX_STAMP(5);
+  }
+
+  MFX_STAMP(6);
+  // ---- exact stage (same as fit_k2.hip phase 3): reference arithmetic and order on the short list
+  auto exact_pair = [&](int i, int j, double& w0, double& w1, double& res) {
+    double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < M; ++m) {
+      const double d1 = elem(0, m, i), d2 = elem(1, m, j), ym = s_y[m];
+      a11 += d1 * d1;
+      a22 += d2 * d2;
+      a12 += d1 * d2;
+      y1 += ym * d1;
+      y2 += ym * d2;
+    }
+    nnls2_exact(y_sq, a11, a12, a22, y1, y2, w0, w1, res);
+  };
+  double* s_rres = (double*)smem;        // [8] per-wave partials (B buffers are idle now)
+  long* s_ridx = (long*)(s_rres + 8);    // [8]
+  double* s_rw = (double*)(s_ridx + 8);  // [8][2]
+  double* s_win = s_rw + 16;             // winner: res, w0, w1, (long) idx
+  auto block_argmin = [&](double res, long idx, double w0, double w1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double r2 = __shfl_xor(res, o), u0 = __shfl_xor(w0, o), u1 = __shfl_xor(w1, o);
+      const long i2 = __shfl_xor(idx, o);
+      const bool take = (r2 < res) || (r2 == res && i2 < idx);
+      res = take ? r2 : res; idx = take ? i2 : idx; w0 = take ? u0 : w0; w1 = take ? u1 : w1;
+    }
+    __syncthreads();
+    if (lane == 0) { s_rres[wave] = res; s_ridx[wave] = idx; s_rw[2 * wave] = w0; s_rw[2 * wave + 1] = w1; }
+    __syncthreads();
+    if (tid == 0) {
+      double br = s_win[0], b0 = s_win[1], b1 = s_win[2];
+      long bi = ((long*)s_win)[3];
+      for (int w = 0; w < NW; ++w) {
+        const double r = s_rres[w];
+        const long ix = s_ridx[w];
+        if (ix < 0) continue;
+        if (r < br || (r == br && bi >= 0 && ix < bi)) { br = r; bi = ix; b0 = s_rw[2 * w]; b1 = s_rw[2 * w + 1]; }
+      }
+      s_win[0] = br; s_win[1] = b0; s_win[2] = b1; ((long*)s_win)[3] = bi;
+    }
+    __syncthreads();
+  };
+  const int nappend = s_cnt[0];
+  const int ncand = nappend > MFX_S_CAP ? MFX_S_CAP : nappend;
+  const double thr_fin = __longlong_as_double((long long)s_thr[0]);
+  const double lost = __longlong_as_double((long long)s_thr[1]);
+  __syncthreads();   // everyone has read the counters / is done with the B buffers
+  if (nappend > MFX_S_CAP && lost >= thr_fin) {
+    // an entry that could still matter was overwritten: hand the voxel to the FP64 kernel
+    if (tid == 0) {
+      const int slot = atomicAdd(a.fb_count, 1);
+      a.fb_list[slot] = vox;
+    }
+    return;
+  }
+  if (tid == 0) {    // mf_utils.py:327, 382: start from min_obj = y_sq at pair (0,0) with w = 0, strict '<'
+    s_win[0] = y_sq; s_win[1] = 0.0; s_win[2] = 0.0; ((long*)s_win)[3] = -1;
+  }
+  {
+    double res = INFINITY, w0 = 0.0, w1 = 0.0;
+    long idx = -1;
+#ifdef MFX_STAMPS
+    double dbg_err = 0.0;
+    int dbg_eval = 0;
+#endif
+    for (int cix = tid; cix < ncand; cix += WG) {
+      if (s_cand[cix].score >= thr_fin) {
+        double r, u0, u1;
+        const int i = s_cand[cix].i, j = s_cand[cix].j;
+        exact_pair(i, j, u0, u1, r);
+        const long ix = (long)i * N + j;
+        if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+#ifdef MFX_STAMPS
+        ++dbg_eval;
+        if (s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+#endif
+      }
+    }
+#ifdef MFX_STAMPS
+    if (a.stamps) {
+      atomicMax(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)__double_as_longlong(dbg_err));
+      atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)dbg_eval);
+      if (tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nappend;
+    }
+#endif
+    block_argmin(res, idx, w0, w1);
+  }
+  // near-zero second weight: evaluate the winner's whole row / column family exactly (see fit_k2.hip)
+  for (int pass = 0; pass < 2; ++pass) {
+    const double bw0 = s_win[1], bw1 = s_win[2];
+    const long bidx = ((long*)s_win)[3];
+    if (bidx < 0) break;
+    const int bi = (int)(bidx / N), bj2 = (int)(bidx - (long)bi * N);
+    const bool row_family = (pass == 0) && (bw1 <= 1e-7 * bw0);
+    const bool col_family = (pass == 1) && (bw0 <= 1e-7 * bw1);
+    if (!row_family && !col_family) continue;
+    double res = INFINITY, w0 = 0.0, w1 = 0.0;
+    long idx = -1;
+    for (int n = tid; n < N; n += WG) {
+      double r, u0, u1;
+      const int i = row_family ? bi : n, j = row_family ? n : bj2;
+      exact_pair(i, j, u0, u1, r);
+      const long ix = (long)i * N + j;
+      if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+    }
+    block_argmin(res, idx, w0, w1);
+  }
+  MFX_STAMP(7);
+  if (wave == 0) {
+    const double best = s_win[0], w0 = s_win[1], w1 = s_win[2];
+    const long bidx = ((long*)s_win)[3];
+    const int bi = bidx < 0 ? 0 : (int)(bidx / N);
+    const int bjx = bidx < 0 ? 0 : (int)(bidx - (long)bi * N);
+    // params packing, mf.py:420-450
+    const double M0 = w0 + w1;
+    const double nu0 = (fabs(M0) > 0) ? w0 / M0 : w0;
+    const double nu1 = (fabs(M0) > 0) ? w1 / M0 : w1;
+    double* s_yrec = s_win + 8;  // [MP] scratch inside the (now idle) B buffers
+    double sy = 0.0, sr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double yr = elem(0, m, bi) * w0 + elem(1, m, bjx) * w1;
+      s_yrec[m] = yr;
+      sy += s_y[m];
+      sr += yr;
+    }
+    sy = wave_sum(sy) / M;
+    sr = wave_sum(sr) / M;
+    double cyy = 0.0, crr = 0.0, cyr = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double da = s_y[m] - sy, db = s_yrec[m] - sr;
+      cyy += da * da;
+      crr += db * db;
+      cyr += da * db;
+    }
+    cyy = wave_sum(cyy);
+    crr = wave_sum(crr);
+    cyr = wave_sum(cyr);
+    double r2 = 0.0;
+    if (M > 1 && cyy > 0.0 && crr > 0.0) {
+      const double f = (double)(M - 1);
+      double r = (cyr / f) / sqrt(cyy / f) / sqrt(crr / f);
+      r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+      r2 = r * r;
+    }
+    double* out = a.params + (size_t)vox * a.num_params;
+    if (lane == 0) {
+      out[0] = M0;
+      out[1] = nu0;
+      out[2] = nu1;
+      out[1 + a.maxfasc] = (double)bi;
+      out[2 + a.maxfasc] = (double)bjx;
+      out[a.num_params - 2] = best / M;
+      out[a.num_params - 1] = r2;
+    }
+  }
+  MFX_STAMP(8);
+}

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "fit_k2.hip"
+#include "fit_k2s.hip"
 #include "fit_small.hip"
 #include "fit_k2x.hip"
 #include "rotate.hip"
@@ -266,7 +267,7 @@ static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
   return MFX_OK;
 }
 
-static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
+static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
   const int M = a.P.M;
   const bool br = a.P.any_bracket != 0;
   if (M <= 64) return br ? launch_k2_t<16, true>(a, nvox, st) : launch_k2_t<16, false>(a, nvox, st);
@@ -275,6 +276,64 @@ static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   if (M <= 400) return br ? launch_k2_t<100, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<100, false, false, 4, 1, 1>(a, nvox, st);
   if (M <= 560) return br ? launch_k2_t<140, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<140, false, false, 4, 1, 1>(a, nvox, st);
   return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 560 (got %d)", M);
+}
+
+// ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
+static size_t k2s_lds_bytes(int KS, int N) {
+  const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
+  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4);
+}
+static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
+static thread_local int g_last_fallback = 0;
+extern "C" int mfx_debug_last_fallback_count(void) { return g_last_fallback; }
+extern "C" void mfx_debug_set_k2_screen(int enabled) { g_k2_screen = enabled ? 1 : 0; }
+
+template <int KS>
+static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
+  const size_t lds = k2s_lds_bytes(KS, a.T.N);
+  auto kern = mfx_fit_k2s_kernel<KS>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int* fb = nullptr;   // [0] count, [1..] voxel list
+  HIPCHK(hipMallocAsync((void**)&fb, sizeof(int) * ((size_t)nvox + 1), st));
+  HIPCHK(hipMemsetAsync(fb, 0, sizeof(int), st));
+  if (g_profiling) {
+    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
+    HIPCHK(hipEventRecord(g_ev0, st));
+  }
+  FitK2Args aa = a;
+  aa.stamps = g_stamps;
+  aa.fb_count = fb;
+  aa.fb_list = fb + 1;
+  hipLaunchKernelGGL(kern, dim3(nvox), dim3(512), lds, st, aa);
+  HIPCHK(hipGetLastError());
+  if (g_profiling) HIPCHK(hipEventRecord(g_ev1, st));
+  int nfb = 0;
+  HIPCHK(hipMemcpyAsync(&nfb, fb, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  g_last_fallback = nfb;
+  int rc = MFX_OK;
+  if (nfb > 0) {           // voxels whose short list overflowed: redo them with the FP64 kernel
+    const bool prof = g_profiling;
+    g_profiling = false;   // keep the event pair of the screening kernel
+    FitK2Args ab = a;
+    ab.vox_list = fb + 1;
+    rc = launch_k2_f64(ab, nfb, st);
+    g_profiling = prof;
+  }
+  if (g_profiling) { g_ev_launches = 1; g_ev_valid = true; }
+  HIPCHK(hipFreeAsync(fb, st));
+  return rc;
+}
+
+static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
+  if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
+  const int M = a.P.M;
+  if (g_k2_screen && !a.P.any_bracket && M <= 208 && k2s_lds_bytes(13, a.T.N) <= 160 * 1024) {
+    if (M <= 64) return launch_k2s_t<4>(a, nvox, st);
+    if (M <= 128) return launch_k2s_t<8>(a, nvox, st);
+    return launch_k2s_t<13>(a, nvox, st);
+  }
+  return launch_k2_f64(a, nvox, st);
 }
 
 // ---- extra (voxel-independent) columns of one voxel class: [csf] + [ear_0..ear_{E-1}]
