@@ -38,8 +38,12 @@ __device__ __forceinline__ unsigned long long mfx_nonneg_bits(double x) {
   return (unsigned long long)__double_as_longlong(x > 0.0 ? x : 0.0);
 }
 
-__device__ __forceinline__ void mfx_split16(double v, _Float16& hi, _Float16& lo) {
-  const float f = (float)v;
+__device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo) {
+  // f must be ONE rounded FP32 value for both uses below.  Without this barrier the compiler folds the
+  // producing multiply into v_fma_mixlo_f16 for the subtraction while the stored hi comes from
+  // v_cvt_pk_f16_f32 of the rounded product: the two differ by an FP16 ulp in double-rounding cases and
+  // the pair (hi, lo) then misses f by 2^-11 |f| (seen as rare 1e-5 |y|^2 screening errors).
+  asm("" : "+v"(f));   // not volatile: an opaque value, free to schedule
   hi = (_Float16)f;
   lo = (_Float16)((f - (float)hi) * 2048.0f);
 }
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   unsigned long long* s_thr = (unsigned long long*)(s_cand + MFX_S_CAP);  // [0] threshold bits, [1] lost-entry max bits
   int* s_r0 = (int*)(s_thr + 2);                   // [2][MP] knot row * ldn (element offset of the row in the table)
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
+  float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -84,12 +89,16 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
     s_r0[idx] = rd.r0 * ldn;
     s_t0[idx] = rd.t0;
+    s_t0f[idx] = (float)rd.t0;
   }
   if (tid == 0) { s_cnt[0] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
   __syncthreads();
 
   // table entry (row offset ro, atom n) through a 32-bit element offset: SGPR base + VGPR offset addressing
   auto tab_at = [&](int ro, int n) -> double2 { return *(const double2*)((const char*)tab + ((unsigned)(ro + n) << 4)); };
+  // the FP32 copy of the table feeds everything that only RANKS pairs (half the L2 -> CU bytes)
+  const float2* __restrict__ tab32 = a.T.tab32;
+  auto tab32_at = [&](int ro, int n) -> float2 { return *(const float2*)((const char*)tab32 + ((unsigned)(ro + n) << 3)); };
   // exact-arithmetic rotated dictionary entry: slope * t + y_lo, separate mul and add (mfx_eval)
   auto elem = [&](int k, int m, int n) -> double {
     const double2 e = tab_at(s_r0[k * MP + m], n);
@@ -108,10 +117,10 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     const int k = col >= NP, n = col - k * NP;
     double a2 = 0.0, ay = 0.0;
     if (n < N) {
-#pragma unroll 8
+#pragma unroll 20
       for (int m = 0; m < M; ++m) {  // ranking statistics only (the exact stage re-sums in reference order)
-        const double2 e = tab_at(s_r0[k * MP + m], n);
-        const double d = fma(e.y, s_t0[k * MP + m], e.x);
+        const float2 e = tab32_at(s_r0[k * MP + m], n);
+        const double d = (double)fmaf(e.y, s_t0f[k * MP + m], e.x);
         a2 = fma(d, d, a2);
         ay = fma(s_y[m], d, ay);
       }
@@ -172,15 +181,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     for (int item = tid; item < 32 * 4 * KS; item += WG) {
       const int c = item & 31, q = item >> 5;
       const int n = ch * 32 + c;
-      const double sc = s_I2[n];
+      const float sc = (float)s_I2[n];
       const int nn = min(n, ldn - 1);
       h4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = 4 * q + e;
-        const double2 d = tab_at(s_r0[MP + m], nn);
+        const float2 d = tab32_at(s_r0[MP + m], nn);
         _Float16 x, y;
-        mfx_split16(fma(d.y, s_t0[MP + m], d.x) * sc, x, y);
+        mfx_split16(fmaf(d.y, s_t0f[MP + m], d.x) * sc, x, y);
         hi[e] = x; lo[e] = y;
       }
       const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
@@ -212,18 +221,18 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     h8 afh[KS], afl[KS];
     {
       const int n = rtc * 32 + lr;
-      const double asc = rt_valid ? s_I1[n] : 0.0;
+      const float asc = rt_valid ? (float)s_I1[n] : 0.0f;
       const int nn = min(n, ldn - 1);
       mfx_static_for<0, KS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
-        double2 d[8];
+        float2 d[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = tab_at(s_r0[16 * ks + 8 * lh + j], nn);
+        for (int j = 0; j < 8; ++j) d[j] = tab32_at(s_r0[16 * ks + 8 * lh + j], nn);
         h8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           _Float16 x, y;
-          mfx_split16(fma(d[j].y, s_t0[16 * ks + 8 * lh + j], d[j].x) * asc, x, y);
+          mfx_split16(fmaf(d[j].y, s_t0f[16 * ks + 8 * lh + j], d[j].x) * asc, x, y);
           vh[j] = x; vl[j] = y;
         }
         asm volatile("" : "+v"(vh), "+v"(vl));   // materialise here: the conversions must not sink below all loads

@@ -70,6 +70,7 @@ struct mfx_tables {
   void* dx = nullptr;
   void* doff = nullptr;
   void* dtab = nullptr;
+  void* dtab32 = nullptr;
   void* dG = nullptr;
 };
 
@@ -127,6 +128,12 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
   HIPCHK(hipMemcpy(t->doff, shell_off, sizeof(int) * (S + 1), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(t->dtab, tab.data(), sizeof(double2) * tab.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(t->dG, G_un, sizeof(double) * S, hipMemcpyHostToDevice));
+  {
+    std::vector<float2> tab32(tab.size());
+    for (size_t q = 0; q < tab.size(); ++q) tab32[q] = float2{(float)tab[q].x, (float)tab[q].y};
+    HIPCHK(hipMalloc(&t->dtab32, sizeof(float2) * tab32.size()));
+    HIPCHK(hipMemcpy(t->dtab32, tab32.data(), sizeof(float2) * tab32.size(), hipMemcpyHostToDevice));
+  }
   t->d.S = S;
   t->d.N = N;
   t->d.ldn = ldn;
@@ -134,6 +141,7 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
   t->d.x = (const double*)t->dx;
   t->d.off = (const int*)t->doff;
   t->d.tab = (const double2*)t->dtab;
+  t->d.tab32 = (const float2*)t->dtab32;
   t->d.G_un = (const double*)t->dG;
   *out = t;
   return MFX_OK;
@@ -145,6 +153,7 @@ extern "C" void mfx_tables_destroy(mfx_tables* t) {
   (void)hipFree(t->dx);
   (void)hipFree(t->doff);
   (void)hipFree(t->dtab);
+  (void)hipFree(t->dtab32);
   (void)hipFree(t->dG);
   delete t;
 }
@@ -281,7 +290,7 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
 static size_t k2s_lds_bytes(int KS, int N) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4);
+  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
 static thread_local int g_last_fallback = 0;

@@ -19,6 +19,7 @@ struct TablesDev {
   const double* x;     // [P]
   const int* off;      // [S+1]
   const double2* tab;  // [(P+1) x ldn]
+  const float2* tab32; // [(P+1) x ldn] the same entries rounded to FP32 (pair screening only, fit_k2s.hip)
   const double* G_un;  // [S]
 };
 
