@@ -28,6 +28,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFX_S_CAP 1024      // ring entries (power of two)
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_r0 = (int*)(s_thr + 2);                   // [2][MP] knot row * ldn (element offset of the row in the table)
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
+  float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
   const double mrg = MFX_S_DC * y_sq;        // |S(c~) - S(c)| <= mrg
   const double etol = MFX_S_DC * sqrt(y_sq); // |e(c~) - e(c)| <= etol
+  const float slackf = (float)(4e-6 * y_sq), etolf = (float)(1.05 * etol);   // FP32 fast pass: see the pair screen
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
   for (int col = tid; col < 2 * NP; col += WG) {
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     const double z = ay * inv;
     (k ? s_I2 : s_I1)[n] = inv;
     (k ? s_Z2 : s_Z1)[n] = (n < N) ? z : -INFINITY;
+    s_Zf[k * NP + n] = (n < N) ? (float)z : -1e30f;
     const double s = z > 0.0 ? z * z : 0.0;
     if (n < N && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }
   }
@@ -176,25 +180,38 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   }
   __syncthreads();
 
-  // generation of one 32-atom chunk of normalised D2 as FP16 hi/lo fragments: item = (atom c, 4 consecutive rows)
-  auto gen_chunk = [&](int ch, int buf) {
-    for (int item = tid; item < 32 * 4 * KS; item += WG) {
-      const int c = item & 31, q = item >> 5;
-      const int n = ch * 32 + c;
-      const float sc = (float)s_I2[n];
-      const int nn = min(n, ldn - 1);
-      h4 hi, lo;
+  // generation of one 32-atom chunk of normalised D2 as FP16 hi/lo fragments: item = (atom c, 4 consecutive rows),
+  // NIT items per thread.  Split in two so that the table loads of chunk ch+1 fly while chunk ch multiplies:
+  // gen_load issues them, gen_store converts and writes the LDS image.
+  constexpr int NIT = (32 * 4 * KS + WG - 1) / WG;
+  float2 gd[NIT][4];
+  auto gen_load = [&](int ch) {
+    const int nn = min(ch * 32 + (tid & 31), ldn - 1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = 4 * q + e;
-        const float2 d = tab32_at(s_r0[MP + m], nn);
-        _Float16 x, y;
-        mfx_split16(fmaf(d.y, s_t0f[MP + m], d.x) * sc, x, y);
-        hi[e] = x; lo[e] = y;
+    for (int it = 0; it < NIT; ++it) {
+      const int q = min((tid >> 5) + 16 * it, 4 * KS - 1);   // the last pass is partial: clamp, gen_store skips
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gd[it][e] = tab32_at(s_r0[MP + 4 * q + e], nn);
+    }
+  };
+  auto gen_store = [&](int ch, int buf) {
+    const int c = tid & 31;
+    const float sc = (float)s_I2[ch * 32 + c];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = (tid >> 5) + 16 * it;
+      if (q < 4 * KS) {
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 x, y;
+          mfx_split16(fmaf(gd[it][e].y, s_t0f[MP + 4 * q + e], gd[it][e].x) * sc, x, y);
+          hi[e] = x; lo[e] = y;
+        }
+        const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
+        *(h4*)(sBh + buf * KS * 512 + off) = hi;
+        *(h4*)(sBl + buf * KS * 512 + off) = lo;
       }
-      const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
-      *(h4*)(sBh + buf * KS * 512 + off) = hi;
-      *(h4*)(sBl + buf * KS * 512 + off) = lo;
     }
   };
 
@@ -240,21 +257,22 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    double z1r[16];
+    float z1f[16];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) z1r[g] = s_Z1[rtc * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh];
+    for (int g = 0; g < 16; ++g) z1f[g] = s_Zf[rtc * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh];
 
     if (round == 0) MFX_STAMP(3);
-    gen_chunk(0, 0);
+    gen_load(0);
+    gen_store(0, 0);
     __syncthreads();
     if (round == 0) MFX_STAMP(4);
     double thr = __longlong_as_double((long long)s_thr[0]);
 
     for (int ch = 0; ch < ntiles; ++ch) {
       const int buf = ch & 1;
-      if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+      if (ch + 1 < ntiles) gen_load(ch + 1);   // consumed after the MFMA loop
+      f32x16 acc_h, acc_x;
       if (rt_valid) {
-        f32x16 acc_h, acc_x;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
         const _Float16* bhp = sBh + buf * KS * 512 + lane * 8;
@@ -273,41 +291,89 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           bh = bhn; bl = bln;
           __builtin_amdgcn_sched_barrier(0);
         });
-        // pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr
+      }
+      if (ch + 1 < ntiles) gen_store(ch + 1, buf ^ 1);   // the loads were issued before the MFMA loop
+      if (rt_valid) {
+        // ---- pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr.
+        // Fast pass in packed FP32, branch-free: per pair the value
+        //     m = min(e1 + etol, e2 + etol, max(f + slack, DENMIN - den, -0.5 - c)),   f = num - thr*den
+        // is >= 0 exactly when the FP64 criteria below COULD hold (slack = 4e-6 |y|^2 covers the FP32
+        // evaluation error of f, < 1e-6 |y|^2 for |z| <= |y|, |c| <= 1); the maxima of m over the four
+        // register groups decide whether the (rare) exact FP64 pass runs for a group.
         thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
         const int j = ch * 32 + lr;
-        const double z2 = s_Z2[j];
+        const float z2f = s_Zf[NP + j];
+        const f32x2 z2v = {z2f, z2f};
+        const float thrf = (float)thr * (1.0f - 2e-7f);   // rounded down
+        const f32x2 nthr = {-thrf, -thrf};
+        float mm[4];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
-          const double z1 = z1r[g];
-          const double e1 = fma(-c, z2, z1);
-          const double e2 = fma(-c, z1, z2);
-          const double den = fma(-c, c, 1.0);
-          const double num = fma(z2, e2, z1 * e1);
-          const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
-          const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
-          const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
-          const bool near = pos & !wellc;
-          if (__any(hit | near)) {   // wave-uniform, rare once thr is close to the optimum
-            double S = -1.0;
-            if (hit) {
-              S = num / den;
-            } else if (near) {
-              // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
-              // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
-              const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
-              const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
-              S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
+        for (int q = 0; q < 4; ++q) {
+          float mq = -1.0f;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int g = 4 * q + 2 * p;
+            const f32x2 ah = {acc_h[g], acc_h[g + 1]}, ax = {acc_x[g], acc_x[g + 1]};
+            const f32x2 z1v = {z1f[g], z1f[g + 1]};
+            const f32x2 c = __builtin_elementwise_fma(ax, f32x2{0x1p-11f, 0x1p-11f}, ah);
+            const f32x2 e1 = __builtin_elementwise_fma(-c, z2v, z1v);
+            const f32x2 e2 = __builtin_elementwise_fma(-c, z1v, z2v);
+            const f32x2 den = __builtin_elementwise_fma(-c, c, f32x2{1.0f, 1.0f});
+            const f32x2 t = __builtin_elementwise_fma(z1v, e1, f32x2{slackf, slackf});
+            const f32x2 num = __builtin_elementwise_fma(z2v, e2, t);
+            const f32x2 f = __builtin_elementwise_fma(nthr, den, num);
+            const f32x2 dn = __builtin_elementwise_fma(c, c, f32x2{(float)MFX_S_DENMIN - 1.0f, (float)MFX_S_DENMIN - 1.0f});
+            const f32x2 cn = f32x2{-0.5f, -0.5f} - c;
+            const f32x2 p1 = e1 + f32x2{etolf, etolf}, p2 = e2 + f32x2{etolf, etolf};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const float ev = fmaxf(fmaxf(f[u], dn[u]), cn[u]);      // v_max3_f32
+              const float m = fminf(fminf(p1[u], p2[u]), ev);         // v_min3_f32
+              mq = fmaxf(mq, m);
             }
-            // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not a
-            // score and never raises it), then append only what still reaches it: no burst of stale entries
-            const double smax = wave_max(hit ? S : 0.0);
-            if (smax - 2.0 * mrg > thr) {
-              thr = smax - 2.0 * mrg;
-              if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
+          }
+          mm[q] = mq;
+        }
+        if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
+          // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
+          const double z2 = s_Z2[j];
+#pragma unroll 1
+          for (int q = 0; q < 4; ++q) {
+            if (!__any(mm[q] >= 0.0f)) continue;
+#pragma unroll 1
+            for (int gg = 0; gg < 4; ++gg) {
+              const int g = 4 * q + gg;
+              const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+              const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
+              const double z1 = s_Z1[i];
+              const double e1 = fma(-c, z2, z1);
+              const double e2 = fma(-c, z1, z2);
+              const double den = fma(-c, c, 1.0);
+              const double num = fma(z2, e2, z1 * e1);
+              const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
+              const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
+              const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
+              const bool near = pos & !wellc;
+              if (!__any(hit | near)) continue;
+              double S = -1.0;
+              if (hit) {
+                S = num / den;
+              } else if (near) {
+                // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
+                // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
+                const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
+                const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
+                S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
+              }
+              // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
+              // a score and never raises it), then append only what still reaches it: no burst of stale entries
+              const double smax = wave_max(hit ? S : 0.0);
+              if (smax - 2.0 * mrg > thr) {
+                thr = smax - 2.0 * mrg;
+                if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
+              }
+              if ((hit | near) && S >= thr) push(S, i, j);
             }
-            if ((hit | near) && S >= thr) push(S, rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh, j);
           }
         }
       }
