@@ -29,6 +29,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFX_S_CAP 1024      // ring entries (power of two)
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
@@ -180,41 +181,6 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   }
   __syncthreads();
 
-  // generation of one 32-atom chunk of normalised D2 as FP16 hi/lo fragments: item = (atom c, 4 consecutive rows),
-  // NIT items per thread.  Split in two so that the table loads of chunk ch+1 fly while chunk ch multiplies:
-  // gen_load issues them, gen_store converts and writes the LDS image.
-  constexpr int NIT = (32 * 4 * KS + WG - 1) / WG;
-  float2 gd[NIT][4];
-  auto gen_load = [&](int ch) {
-    const int nn = min(ch * 32 + (tid & 31), ldn - 1);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = min((tid >> 5) + 16 * it, 4 * KS - 1);   // the last pass is partial: clamp, gen_store skips
-#pragma unroll
-      for (int e = 0; e < 4; ++e) gd[it][e] = tab32_at(s_r0[MP + 4 * q + e], nn);
-    }
-  };
-  auto gen_store = [&](int ch, int buf) {
-    const int c = tid & 31;
-    const float sc = (float)s_I2[ch * 32 + c];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = (tid >> 5) + 16 * it;
-      if (q < 4 * KS) {
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          _Float16 x, y;
-          mfx_split16(fmaf(gd[it][e].y, s_t0f[MP + 4 * q + e], gd[it][e].x) * sc, x, y);
-          hi[e] = x; lo[e] = y;
-        }
-        const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
-        *(h4*)(sBh + buf * KS * 512 + off) = hi;
-        *(h4*)(sBl + buf * KS * 512 + off) = lo;
-      }
-    }
-  };
-
   // ring append (rare path)
   auto push = [&](double S, int i, int j) {
     const int slot = atomicAdd(&s_cnt[0], 1);
@@ -231,7 +197,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   MFX_STAMP(2);
   const int nrounds = (ntiles + NW - 1) / NW;
   for (int round = 0; round < nrounds; ++round) {
-    const int rt = round * NW + wave;
+    // A last round with ONE row tile left (N = 782: 25 = 3*8 + 1) is shared by all waves: each keeps the same
+    // A tile and takes every 8th column tile, generating its B operand straight into registers (no LDS image,
+    // no workgroup barrier), instead of 7 waves idling through a full D2 sweep.
+    const bool tail = (ntiles - round * NW == 1) && (ntiles > 1);
+    const int rt = tail ? round * NW : round * NW + wave;
     const bool rt_valid = rt < ntiles;  // wave-uniform
     const int rtc = rt_valid ? rt : 0;
     // A operand: this wave's 32 atoms of D1 (normalised, split), all KS k-steps, in registers
@@ -257,124 +227,216 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    float z1f[16];
+
+    // pair screen of one 32x32 accumulator tile against column tile ct (used by the LDS sweep and by the tail round)
+    double thr = 0.0;
+    auto scan_tile = [&](const f32x16& acc_h, const f32x16& acc_x, int ct) {
+      const int j = ct * 32 + lr;
+      // ---- pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr.
+      // Fast pass in FP32, branch-free: per pair the value
+      //     m = min(e1 + etol, e2 + etol, max(f + slack, DENMIN - den, -0.5 - c)),   f = num - thr*den
+      // is >= 0 exactly when the FP64 criteria below COULD hold (slack = 4e-6 |y|^2 covers the FP32
+      // evaluation error of f, < 1e-6 |y|^2 for |z| <= |y|, |c| <= 1); the maxima of m over the four
+      // register groups decide whether the (rare) exact FP64 pass runs for a group.
+      thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
+      const float z2f = s_Zf[NP + j];
+      const float thrf = (float)thr * (1.0f - 2e-7f);   // rounded down
+      float mm[4];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) z1f[g] = s_Zf[rtc * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh];
+      for (int q = 0; q < 4; ++q) {
+        float mq = -1.0f;
+        const f32x4 z1q = *(const f32x4*)(s_Zf + rtc * 32 + 8 * q + 4 * lh);   // rows (g&3) + 8q + 4 lh, g = 4q..4q+3
+        // plain (not packed) FP32: beside the other wave's MFMAs a v_pk_*_f32 costs several plain ones
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int g = 4 * q + u;
+          const float z1 = z1q[u];
+          const float c = fmaf(acc_x[g], 0x1p-11f, acc_h[g]);
+          const float e1 = fmaf(-c, z2f, z1);
+          const float e2 = fmaf(-c, z1, z2f);
+          const float den = fmaf(-c, c, 1.0f);
+          const float t = fmaf(z1, e1, slackf);
+          const float num = fmaf(z2f, e2, t);
+          const float f = fmaf(-thrf, den, num);
+          const float dn = (float)MFX_S_DENMIN - den;
+          const float cn = -0.5f - c;
+          const float ev = fmaxf(fmaxf(f, dn), cn);                        // v_max3_f32
+          const float m = fminf(fminf(e1 + etolf, e2 + etolf), ev);        // v_min3_f32
+          mq = fmaxf(mq, m);
+        }
+        mm[q] = mq;
+      }
+      if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
+        // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
+        const double z2 = s_Z2[j];
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+          if (!__any(mm[q] >= 0.0f)) continue;
+#pragma unroll 1
+          for (int gg = 0; gg < 4; ++gg) {
+            const int g = 4 * q + gg;
+            const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+            const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
+            const double z1 = s_Z1[i];
+            const double e1 = fma(-c, z2, z1);
+            const double e2 = fma(-c, z1, z2);
+            const double den = fma(-c, c, 1.0);
+            const double num = fma(z2, e2, z1 * e1);
+            const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
+            const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
+            const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
+            const bool near = pos & !wellc;
+            if (!__any(hit | near)) continue;
+            double S = -1.0;
+            if (hit) {
+              S = num / den;
+            } else if (near) {
+              // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
+              // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
+              const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
+              const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
+              S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
+            }
+            // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
+            // a score and never raises it), then append only what still reaches it: no burst of stale entries
+            const double smax = wave_max(hit ? S : 0.0);
+            if (smax - 2.0 * mrg > thr) {
+              thr = smax - 2.0 * mrg;
+              if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
+            }
+            if ((hit | near) && S >= thr) push(S, i, j);
+          }
+        }
+      }
+    };
 
-    if (round == 0) MFX_STAMP(3);
-    gen_load(0);
-    gen_store(0, 0);
-    __syncthreads();
-    if (round == 0) MFX_STAMP(4);
-    double thr = __longlong_as_double((long long)s_thr[0]);
-
-    for (int ch = 0; ch < ntiles; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < ntiles) gen_load(ch + 1);   // consumed after the MFMA loop
-      f32x16 acc_h, acc_x;
-      if (rt_valid) {
+    if (tail) {
+      thr = __longlong_as_double((long long)s_thr[0]);
+      for (int ct = wave; ct < ntiles; ct += NW) {
+        const int n = ct * 32 + lr;
+        const float bsc = (float)s_I2[n];
+        const int nn = min(n, ldn - 1);
+        f32x16 acc_h, acc_x;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
-        const _Float16* bhp = sBh + buf * KS * 512 + lane * 8;
-        const _Float16* blp = sBl + buf * KS * 512 + lane * 8;
-        h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
+        float2 d[2][8];   // table entries of k-step ks (in use) and ks+1 (in flight)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[0][j] = tab32_at(s_r0[MP + 8 * lh + j], nn);
         mfx_static_for<0, KS>([&](auto kc) {
           constexpr int ks = decltype(kc)::value;
-          h8 bhn = bh, bln = bl;
-          if constexpr (ks + 1 < KS) {   // fragments of the next k-step while this one multiplies
-            bhn = *(const h8*)(bhp + (ks + 1) * 512);
-            bln = *(const h8*)(blp + (ks + 1) * 512);
+          if constexpr (ks + 1 < KS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[(ks + 1) & 1][j] = tab32_at(s_r0[MP + 16 * (ks + 1) + 8 * lh + j], nn);
+          }
+          h8 bh, bl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            _Float16 x, y;
+            mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x) * bsc, x, y);
+            bh[j] = x; bl[j] = y;
           }
           acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc_h, 0, 0, 0);
           acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc_x, 0, 0, 0);
           acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc_x, 0, 0, 0);
-          bh = bhn; bl = bln;
           __builtin_amdgcn_sched_barrier(0);
         });
+        scan_tile(acc_h, acc_x, ct);
       }
-      if (ch + 1 < ntiles) gen_store(ch + 1, buf ^ 1);   // the loads were issued before the MFMA loop
-      if (rt_valid) {
-        // ---- pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr.
-        // Fast pass in packed FP32, branch-free: per pair the value
-        //     m = min(e1 + etol, e2 + etol, max(f + slack, DENMIN - den, -0.5 - c)),   f = num - thr*den
-        // is >= 0 exactly when the FP64 criteria below COULD hold (slack = 4e-6 |y|^2 covers the FP32
-        // evaluation error of f, < 1e-6 |y|^2 for |z| <= |y|, |c| <= 1); the maxima of m over the four
-        // register groups decide whether the (rare) exact FP64 pass runs for a group.
-        thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
-        const int j = ch * 32 + lr;
-        const float z2f = s_Zf[NP + j];
-        const f32x2 z2v = {z2f, z2f};
-        const float thrf = (float)thr * (1.0f - 2e-7f);   // rounded down
-        const f32x2 nthr = {-thrf, -thrf};
-        float mm[4];
+      __syncthreads();   // all appends of the round are in the ring
+      continue;
+    }
+
+    // ---- LDS sweep, ping-pong between the two wave groups (waves 0-3 | 4-7: one wave of each per SIMD).
+    // In every half-step one group runs the 3*KS MFMAs of a column chunk while the other one does VALU work
+    // (pair screen of its previous accumulator tile + its half of the generation of a coming chunk), so the
+    // matrix pipe and the vector ALUs of a SIMD are busy at the same time; a workgroup barrier ends each
+    // half-step.  Group g multiplies chunk c in half-step 2c+g and screens it in half-step 2c+g+1.
+    // Chunk c lives in LDS buffer c&1: it is read in half-steps 2c, 2c+1 and written in 2c-2 (group 1's half)
+    // and 2c-1 (group 0's half), i.e. while buffer (c-1)&1 is being read.
+    // Generation item = (atom col, 4 consecutive rows); a group owns 2*KS of the 4*KS row quads of a chunk.
+    // gen_load issues the table loads at the start of the group's MFMA half-step, gen_store converts and writes
+    // the FP16 hi/lo fragments in its next VALU half-step (the loads fly behind the MFMAs).
+    const int grp = wave >> 2, tg = tid & 255;
+    constexpr int NITG = (2 * KS + 7) / 8;
+    float2 gd[NITG][4];
+    auto gen_load = [&](int ch) {
+      const int nn = min(ch * 32 + (tg & 31), ldn - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float mq = -1.0f;
+      for (int it = 0; it < NITG; ++it) {
+        const int q = 2 * KS * grp + min((tg >> 5) + 8 * it, 2 * KS - 1);   // a partial last pass is clamped, gen_store skips it
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const int g = 4 * q + 2 * p;
-            const f32x2 ah = {acc_h[g], acc_h[g + 1]}, ax = {acc_x[g], acc_x[g + 1]};
-            const f32x2 z1v = {z1f[g], z1f[g + 1]};
-            const f32x2 c = __builtin_elementwise_fma(ax, f32x2{0x1p-11f, 0x1p-11f}, ah);
-            const f32x2 e1 = __builtin_elementwise_fma(-c, z2v, z1v);
-            const f32x2 e2 = __builtin_elementwise_fma(-c, z1v, z2v);
-            const f32x2 den = __builtin_elementwise_fma(-c, c, f32x2{1.0f, 1.0f});
-            const f32x2 t = __builtin_elementwise_fma(z1v, e1, f32x2{slackf, slackf});
-            const f32x2 num = __builtin_elementwise_fma(z2v, e2, t);
-            const f32x2 f = __builtin_elementwise_fma(nthr, den, num);
-            const f32x2 dn = __builtin_elementwise_fma(c, c, f32x2{(float)MFX_S_DENMIN - 1.0f, (float)MFX_S_DENMIN - 1.0f});
-            const f32x2 cn = f32x2{-0.5f, -0.5f} - c;
-            const f32x2 p1 = e1 + f32x2{etolf, etolf}, p2 = e2 + f32x2{etolf, etolf};
+        for (int e = 0; e < 4; ++e) gd[it][e] = tab32_at(s_r0[MP + 4 * q + e], nn);
+      }
+    };
+    auto gen_store = [&](int ch) {
+      const int c = tg & 31;
+      const float sc = (float)s_I2[ch * 32 + c];
+      _Float16* dh = sBh + (ch & 1) * KS * 512;
+      _Float16* dl = sBl + (ch & 1) * KS * 512;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const float ev = fmaxf(fmaxf(f[u], dn[u]), cn[u]);      // v_max3_f32
-              const float m = fminf(fminf(p1[u], p2[u]), ev);         // v_min3_f32
-              mq = fmaxf(mq, m);
-            }
+      for (int it = 0; it < NITG; ++it) {
+        const int ql = (tg >> 5) + 8 * it;
+        if (ql < 2 * KS) {
+          const int q = 2 * KS * grp + ql;
+          h4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            _Float16 x, y;
+            mfx_split16(fmaf(gd[it][e].y, s_t0f[MP + 4 * q + e], gd[it][e].x) * sc, x, y);
+            hi[e] = x; lo[e] = y;
           }
-          mm[q] = mq;
+          const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
+          *(h4*)(dh + off) = hi;
+          *(h4*)(dl + off) = lo;
         }
-        if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
-          // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
-          const double z2 = s_Z2[j];
-#pragma unroll 1
-          for (int q = 0; q < 4; ++q) {
-            if (!__any(mm[q] >= 0.0f)) continue;
-#pragma unroll 1
-            for (int gg = 0; gg < 4; ++gg) {
-              const int g = 4 * q + gg;
-              const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-              const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
-              const double z1 = s_Z1[i];
-              const double e1 = fma(-c, z2, z1);
-              const double e2 = fma(-c, z1, z2);
-              const double den = fma(-c, c, 1.0);
-              const double num = fma(z2, e2, z1 * e1);
-              const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
-              const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
-              const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
-              const bool near = pos & !wellc;
-              if (!__any(hit | near)) continue;
-              double S = -1.0;
-              if (hit) {
-                S = num / den;
-              } else if (near) {
-                // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
-                // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
-                const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
-                const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
-                S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
+      }
+    };
+
+    if (round == 0) MFX_STAMP(3);
+    // prologue: chunk 0 (both halves) and group 1's half of chunk 1
+    gen_load(0);
+    gen_store(0);
+    if (grp == 1 && ntiles > 1) { gen_load(1); gen_store(1); }
+    __syncthreads();
+    if (round == 0) MFX_STAMP(4);
+    thr = __longlong_as_double((long long)s_thr[0]);
+
+    f32x16 acc_h, acc_x;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+    for (int hs = 0; hs <= 2 * ntiles; ++hs) {
+      if ((hs & 1) == grp) {
+        // ---- MFMA half-step: chunk c = (hs - grp) / 2
+        const int c = (hs - grp) >> 1;
+        if (c < ntiles) {
+          if (c + 1 + grp < ntiles) gen_load(c + 1 + grp);   // consumed in this group's next half-step
+          if (rt_valid) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+            const _Float16* bhp = sBh + (c & 1) * KS * 512 + lane * 8;
+            const _Float16* blp = sBl + (c & 1) * KS * 512 + lane * 8;
+            h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
+            mfx_static_for<0, KS>([&](auto kc) {
+              constexpr int ks = decltype(kc)::value;
+              h8 bhn = bh, bln = bl;
+              if constexpr (ks + 1 < KS) {   // fragments of the next k-step while this one multiplies
+                bhn = *(const h8*)(bhp + (ks + 1) * 512);
+                bln = *(const h8*)(blp + (ks + 1) * 512);
               }
-              // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
-              // a score and never raises it), then append only what still reaches it: no burst of stale entries
-              const double smax = wave_max(hit ? S : 0.0);
-              if (smax - 2.0 * mrg > thr) {
-                thr = smax - 2.0 * mrg;
-                if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
-              }
-              if ((hit | near) && S >= thr) push(S, i, j);
-            }
+              acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc_h, 0, 0, 0);
+              acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc_x, 0, 0, 0);
+              acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc_x, 0, 0, 0);
+              bh = bhn; bl = bln;
+              __builtin_amdgcn_sched_barrier(0);
+            });
           }
+        }
+      } else {
+        // ---- VALU half-step: finish the generation of this group's half of chunk c + 1 + grp, screen chunk c
+        const int c = (hs - 1 - grp) >> 1;
+        if (c >= 0 && c < ntiles) {
+          if (c + 1 + grp < ntiles) gen_store(c + 1 + grp);
+          if (rt_valid) scan_tile(acc_h, acc_x, c);
         }
       }
       __syncthreads();
