@@ -30,6 +30,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define MFX_S_CAP 1024      // ring entries (power of two)
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
@@ -79,12 +80,13 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
   float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
+  float* s_yf = s_Zf + 2 * NP;                     // [MP] FP32 copy of y (ranking statistics)
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
-  for (int m = tid; m < MP; m += WG) s_y[m] = (m < M) ? yv[m] : 0.0;
+  for (int m = tid; m < MP; m += WG) { const double v = (m < M) ? yv[m] : 0.0; s_y[m] = v; s_yf[m] = (float)v; }
   for (int idx = tid; idx < 2 * MP; idx += WG) {
     const int k = idx / MP, m = idx - k * MP;
     RowDesc rd;
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   // the FP32 copy of the table feeds everything that only RANKS pairs (half the L2 -> CU bytes)
   const float2* __restrict__ tab32 = a.T.tab32;
   auto tab32_at = [&](int ro, int n) -> float2 { return *(const float2*)((const char*)tab32 + ((unsigned)(ro + n) << 3)); };
+  // two adjacent atoms (n even) in one 16-byte load: {ylo_n, slope_n, ylo_n+1, slope_n+1}
+  auto tab32x2_at = [&](int ro, int n) -> f32x4 { return *(const f32x4*)((const char*)tab32 + ((unsigned)(ro + n) << 3)); };
   // exact-arithmetic rotated dictionary entry: slope * t + y_lo, separate mul and add (mfx_eval)
   auto elem = [&](int k, int m, int n) -> double {
     const double2 e = tab_at(s_r0[k * MP + m], n);
@@ -117,25 +121,67 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   const float slackf = (float)(4e-6 * y_sq), etolf = (float)(1.05 * etol);   // FP32 fast pass: see the pair screen
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
-  for (int col = tid; col < 2 * NP; col += WG) {
-    const int k = col >= NP, n = col - k * NP;
-    double a2 = 0.0, ay = 0.0;
-    if (n < N) {
-#pragma unroll 20
-      for (int m = 0; m < M; ++m) {  // ranking statistics only (the exact stage re-sums in reference order)
-        const float2 e = tab32_at(s_r0[k * MP + m], n);
-        const double d = (double)fmaf(e.y, s_t0f[k * MP + m], e.x);
-        a2 = fma(d, d, a2);
-        ay = fma(s_y[m], d, ay);
+  {
+    // The vector-memory pipe of a CU retires roughly one wave load per 20 cycles whatever its width (<= 16 B per
+    // lane), and this kernel issues ~1e4 of them per voxel: table entries are therefore fetched two atoms at a
+    // time (16 B: {ylo, slope} of atoms n, n+1).  Column pairs are laid out as v in [0, VH): atoms 2v, 2v+1 of D1,
+    // v in [VH, 2 VH): of D2, VH a multiple of 64 so that the direction is wave-uniform; a thread accumulates its
+    // pairs v = tid + 512 p, all passes at once: independent loads in flight, and the per-row constants (knot
+    // row, offset, y) come from LDS as one 16-byte broadcast read per four rows.
+    // Ranking statistics only (FP32 table, fused ops): the exact stage re-sums in reference order.
+    const int VH = ((N + 1) / 2 + 63) & ~63;
+    const int npass = (2 * VH + WG - 1) / WG;
+    for (int p0 = 0; p0 < npass; p0 += 2) {
+      int kq[2], nq[2];
+      bool wact[2];
+      double a2[2][2], ay[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int v = tid + WG * (p0 + q);
+        kq[q] = v >= VH;
+        nq[q] = 2 * (v - kq[q] * VH);
+        wact[q] = __any((p0 + q < npass) && (nq[q] < N));
+        a2[q][0] = a2[q][1] = ay[q][0] = ay[q][1] = 0.0;
+      }
+      for (int m4 = 0; m4 < MP; m4 += 4) {
+        const f32x4 yv = *(const f32x4*)(s_yf + m4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (wact[q]) {   // wave-uniform
+            const i32x4 r = *(const i32x4*)(s_r0 + kq[q] * MP + m4);
+            const f32x4 t = *(const f32x4*)(s_t0f + kq[q] * MP + m4);
+            const int ncl = min(nq[q], ldn - 2);   // ldn is even: the pair stays inside the row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x4 d = tab32x2_at(r[e], ncl);
+              const double d0 = (double)fmaf(d[1], t[e], d[0]), d1 = (double)fmaf(d[3], t[e], d[2]);
+              const double ye = (double)yv[e];
+              a2[q][0] = fma(d0, d0, a2[q][0]);
+              ay[q][0] = fma(ye, d0, ay[q][0]);
+              a2[q][1] = fma(d1, d1, a2[q][1]);
+              ay[q][1] = fma(ye, d1, ay[q][1]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kq[q], n = nq[q] + u;
+          if (p0 + q < npass && n < NP) {
+            const bool act = n < N;
+            const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
+            const double z = ay[q][u] * inv;
+            (k ? s_I2 : s_I1)[n] = inv;
+            (k ? s_Z2 : s_Z1)[n] = act ? z : -INFINITY;
+            s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+            const double s = z > 0.0 ? z * z : 0.0;
+            if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
+          }
+        }
       }
     }
-    const double inv = (n < N && a2 > 0.0) ? 1.0 / sqrt(a2) : 0.0;
-    const double z = ay * inv;
-    (k ? s_I2 : s_I1)[n] = inv;
-    (k ? s_Z2 : s_Z1)[n] = (n < N) ? z : -INFINITY;
-    s_Zf[k * NP + n] = (n < N) ? (float)z : -1e30f;
-    const double s = z > 0.0 ? z * z : 0.0;
-    if (n < N && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }
   }
   // best single atom of each dictionary (first index on ties): they stand for every pair whose optimum
   // has one active atom (mf_utils.py:357-379); the exact stage expands the winner's family
@@ -357,37 +403,42 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // gen_load issues the table loads at the start of the group's MFMA half-step, gen_store converts and writes
     // the FP16 hi/lo fragments in its next VALU half-step (the loads fly behind the MFMAs).
     const int grp = wave >> 2, tg = tid & 255;
-    constexpr int NITG = (2 * KS + 7) / 8;
-    float2 gd[NITG][4];
+    constexpr int NITG = (2 * KS + 15) / 16;
+    f32x4 gd[NITG][4];   // item = (pair of adjacent atoms, 4 consecutive rows): 16-byte loads, see phase 1
     auto gen_load = [&](int ch) {
-      const int nn = min(ch * 32 + (tg & 31), ldn - 1);
+      const int nn = min(ch * 32 + 2 * (tg & 15), ldn - 2);
 #pragma unroll
       for (int it = 0; it < NITG; ++it) {
-        const int q = 2 * KS * grp + min((tg >> 5) + 8 * it, 2 * KS - 1);   // a partial last pass is clamped, gen_store skips it
+        const int q = 2 * KS * grp + min((tg >> 4) + 16 * it, 2 * KS - 1);   // a partial last pass is clamped, gen_store skips it
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gd[it][e] = tab32_at(s_r0[MP + 4 * q + e], nn);
+        for (int e = 0; e < 4; ++e) gd[it][e] = tab32x2_at(s_r0[MP + 4 * q + e], nn);
       }
     };
     auto gen_store = [&](int ch) {
-      const int c = tg & 31;
-      const float sc = (float)s_I2[ch * 32 + c];
+      const int c0 = 2 * (tg & 15);
+      const float sc0 = (float)s_I2[ch * 32 + c0], sc1 = (float)s_I2[ch * 32 + c0 + 1];
       _Float16* dh = sBh + (ch & 1) * KS * 512;
       _Float16* dl = sBl + (ch & 1) * KS * 512;
 #pragma unroll
       for (int it = 0; it < NITG; ++it) {
-        const int ql = (tg >> 5) + 8 * it;
+        const int ql = (tg >> 4) + 16 * it;
         if (ql < 2 * KS) {
           const int q = 2 * KS * grp + ql;
-          h4 hi, lo;
+          h4 hi0, lo0, hi1, lo1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            const float t = s_t0f[MP + 4 * q + e];
             _Float16 x, y;
-            mfx_split16(fmaf(gd[it][e].y, s_t0f[MP + 4 * q + e], gd[it][e].x) * sc, x, y);
-            hi[e] = x; lo[e] = y;
+            mfx_split16(fmaf(gd[it][e][1], t, gd[it][e][0]) * sc0, x, y);
+            hi0[e] = x; lo0[e] = y;
+            mfx_split16(fmaf(gd[it][e][3], t, gd[it][e][2]) * sc1, x, y);
+            hi1[e] = x; lo1[e] = y;
           }
-          const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c) << 3) + ((q & 1) << 2);
-          *(h4*)(dh + off) = hi;
-          *(h4*)(dl + off) = lo;
+          const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c0) << 3) + ((q & 1) << 2);
+          *(h4*)(dh + off) = hi0;
+          *(h4*)(dl + off) = lo0;
+          *(h4*)(dh + off + 8) = hi1;   // atom c0 + 1: next fragment lane
+          *(h4*)(dl + off + 8) = lo1;
         }
       }
     };
