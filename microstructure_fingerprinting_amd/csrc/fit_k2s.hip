@@ -403,43 +403,36 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // gen_load issues the table loads at the start of the group's MFMA half-step, gen_store converts and writes
     // the FP16 hi/lo fragments in its next VALU half-step (the loads fly behind the MFMAs).
     const int grp = wave >> 2, tg = tid & 255;
-    constexpr int NITG = (2 * KS + 15) / 16;
-    f32x4 gd[NITG][4];   // item = (pair of adjacent atoms, 4 consecutive rows): 16-byte loads, see phase 1
+    static_assert(KS <= 16, "one generation item per thread");
+    f32x4 gd[8];   // item = (pair of adjacent atoms, the 8 rows of one fragment): 16-byte loads, see phase 1
+    const int gq = KS * grp + (tg >> 4);      // fragment row block (k-step, half) = gq; rows 8 gq .. 8 gq + 7
+    const bool gact = (tg >> 4) < KS;
     auto gen_load = [&](int ch) {
       const int nn = min(ch * 32 + 2 * (tg & 15), ldn - 2);
+      const int q = gact ? gq : KS * grp;     // idle threads repeat a valid address, gen_store skips them
 #pragma unroll
-      for (int it = 0; it < NITG; ++it) {
-        const int q = 2 * KS * grp + min((tg >> 4) + 16 * it, 2 * KS - 1);   // a partial last pass is clamped, gen_store skips it
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gd[it][e] = tab32x2_at(s_r0[MP + 4 * q + e], nn);
-      }
+      for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_r0[MP + 8 * q + e], nn);
     };
     auto gen_store = [&](int ch) {
-      const int c0 = 2 * (tg & 15);
-      const float sc0 = (float)s_I2[ch * 32 + c0], sc1 = (float)s_I2[ch * 32 + c0 + 1];
-      _Float16* dh = sBh + (ch & 1) * KS * 512;
-      _Float16* dl = sBl + (ch & 1) * KS * 512;
+      if (gact) {
+        const int c0 = 2 * (tg & 15);
+        const float sc0 = (float)s_I2[ch * 32 + c0], sc1 = (float)s_I2[ch * 32 + c0 + 1];
+        h8 hi0, lo0, hi1, lo1;
 #pragma unroll
-      for (int it = 0; it < NITG; ++it) {
-        const int ql = (tg >> 4) + 16 * it;
-        if (ql < 2 * KS) {
-          const int q = 2 * KS * grp + ql;
-          h4 hi0, lo0, hi1, lo1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = s_t0f[MP + 4 * q + e];
-            _Float16 x, y;
-            mfx_split16(fmaf(gd[it][e][1], t, gd[it][e][0]) * sc0, x, y);
-            hi0[e] = x; lo0[e] = y;
-            mfx_split16(fmaf(gd[it][e][3], t, gd[it][e][2]) * sc1, x, y);
-            hi1[e] = x; lo1[e] = y;
-          }
-          const int off = (((q >> 2) * 64 + ((q >> 1) & 1) * 32 + c0) << 3) + ((q & 1) << 2);
-          *(h4*)(dh + off) = hi0;
-          *(h4*)(dl + off) = lo0;
-          *(h4*)(dh + off + 8) = hi1;   // atom c0 + 1: next fragment lane
-          *(h4*)(dl + off + 8) = lo1;
+        for (int e = 0; e < 8; ++e) {
+          const float t = s_t0f[MP + 8 * gq + e];
+          _Float16 x, y;
+          mfx_split16(fmaf(gd[e][1], t, gd[e][0]) * sc0, x, y);
+          hi0[e] = x; lo0[e] = y;
+          mfx_split16(fmaf(gd[e][3], t, gd[e][2]) * sc1, x, y);
+          hi1[e] = x; lo1[e] = y;
         }
+        // fragments of atoms c0, c0+1 are adjacent: 32 contiguous bytes per lane, conflict-free
+        const int off = (gq * 32 + c0) << 3;
+        _Float16* dh = sBh + (ch & 1) * KS * 512 + off;
+        _Float16* dl = sBl + (ch & 1) * KS * 512 + off;
+        *(h8*)dh = hi0; *(h8*)(dh + 8) = hi1;
+        *(h8*)dl = lo0; *(h8*)(dl + 8) = lo1;
       }
     };
 
