@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         best1 = fmax(best1, s);
         if (s > 0.0) {
           const int slot = s_cnt[0]++;
-          s_cand[slot].score = INFINITY;  // always evaluated
+          s_cand[slot].score = s + mrg;   // exact single-atom score up to the statistics' rounding: evaluated only if it can win
           s_cand[slot].i = k ? 0 : n;
           s_cand[slot].j = k ? n : 0;
         }
@@ -554,8 +554,56 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     double dbg_err = 0.0;
     int dbg_eval = 0;
 #endif
-    for (int cix = tid; cix < ncand; cix += WG) {
-      if (s_cand[cix].score >= thr_fin) {
+    // compact list of the ring entries that reach the final threshold
+    int* s_evl = (int*)((char*)smem + 2048);                       // [MFX_S_CAP], inside the idle hi image (behind s_win / s_yrec)
+    double* s_stage = (double*)sBl + (size_t)wave * 2 * MP;       // [2][MP] per wave, inside the idle lo image
+    if (tid == 0) s_cnt[2] = 0;
+    __syncthreads();
+    for (int cix = tid; cix < ncand; cix += WG)
+      if (s_cand[cix].score >= thr_fin) s_evl[atomicAdd(&s_cnt[2], 1)] = cix;
+    __syncthreads();
+    const int neval = s_cnt[2];
+    if (neval <= 24) {
+      // few candidates (the usual case): one WAVE per candidate.  A thread-per-candidate loop is bound by the
+      // latency of its 2 x 200 dependent-address table loads (51 k cycles whatever the count); here the 64 lanes
+      // fetch the rows side by side, then five lanes run the five sequential sums of mf_utils.py:307-325 from LDS.
+      for (int e = wave; e < neval; e += NW) {
+        const int cix = s_evl[e];
+        const int i = s_cand[cix].i, j = s_cand[cix].j;
+#pragma unroll
+        for (int mb = 0; mb < (MP + 63) / 64; ++mb) {   // all table loads of the pair in flight at once
+          const int m = mb * 64 + lane;
+          if (m < M) {
+            s_stage[m] = elem(0, m, i);
+            s_stage[MP + m] = elem(1, m, j);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // lane 0: a11 = sum d1*d1, 1: a22 = sum d2*d2, 2: a12 = sum d1*d2, 3: y1 = sum y*d1, 4: y2 = sum y*d2
+        const double* pa = (lane == 1) ? s_stage + MP : (lane >= 3 ? s_y : s_stage);
+        const double* pb = (lane == 0 || lane == 3) ? s_stage : s_stage + MP;
+        double acc = 0.0;
+        if (lane < 5) {
+#pragma unroll 16
+          for (int m = 0; m < M; ++m) acc += pa[m] * pb[m];
+        }
+        const double a11 = __shfl(acc, 0), a22 = __shfl(acc, 1), a12 = __shfl(acc, 2), y1 = __shfl(acc, 3), y2 = __shfl(acc, 4);
+        double r, u0, u1;
+        nnls2_exact(y_sq, a11, a12, a22, y1, y2, u0, u1, r);
+        const long ix = (long)i * N + j;
+        if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+#ifdef MFX_STAMPS
+        if (lane == 0) {
+          ++dbg_eval;
+          if (cix >= 2 && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+        }
+#endif
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      for (int e = tid; e < neval; e += WG) {
+        const int cix = s_evl[e];
         double r, u0, u1;
         const int i = s_cand[cix].i, j = s_cand[cix].j;
         exact_pair(i, j, u0, u1, r);
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
 #ifdef MFX_STAMPS
         ++dbg_eval;
-        if (s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+        if (cix >= 2 && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
 #endif
       }
     }
@@ -574,7 +622,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nappend;
     }
 #endif
+    MFX_STAMP(13);
     block_argmin(res, idx, w0, w1);
+    MFX_STAMP(14);
   }
   // near-zero second weight: evaluate the winner's whole row / column family exactly (see fit_k2.hip)
   for (int pass = 0; pass < 2; ++pass) {

@@ -42,6 +42,11 @@ print("total cycles per voxel-WG (median, non-fallback path): %.0f" % tot)
 for nm, a_, b_ in [("phase0 y+descriptors", 0, 1), ("phase1 column stats", 1, 2), ("round0: A operand", 2, 3), ("round0: gen chunk0+barrier", 3, 4),
                    ("round0: chunk loop", 4, 5), ("all rounds (2->6)", 2, 6), ("exact stage", 6, 7), ("outputs", 7, 8)]:
     print("  %-28s %10.0f cycles  %5.1f %%" % (nm, d(a_, b_), 100 * d(a_, b_) / tot))
+print("exact stage split: candidates %d | argmin %d | family passes %d" % (d(6, 13), d(13, 14), d(14, 7)))
+fam = (s[:, 7] - s[:, 14])
+print("family passes: p10 %d p50 %d p90 %d p99 %d" % tuple(np.percentile(fam, [10, 50, 90, 99])))
+can = (s[:, 13] - s[:, 6])
+print("candidates:    p10 %d p50 %d p90 %d p99 %d" % tuple(np.percentile(can, [10, 50, 90, 99])))
 napp = raw[:, 12]
 nev = raw[:, 11]
 err = raw[:, 10].view(np.float64) if raw.dtype == np.int64 else None
