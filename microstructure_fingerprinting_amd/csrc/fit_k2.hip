@@ -195,14 +195,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     } else {
       (k ? s_A22 : s_A11)[n] = a2;
       (k ? s_Y2 : s_Y1)[n] = ay;
-      (k ? s_S2 : s_S1)[n] = (n < N && ay > 0.0) ? (ay * ay) / a2 : 0.0;
+      const double s = (n < N && ay > 0.0) ? (ay * ay) / a2 : 0.0;
+      (k ? s_S2 : s_S1)[n] = s;
+      if (s > my_s[k]) { my_s[k] = s; my_n[k] = n; }
     }
   }
   const double eps_abs = 1e-9 * y_sq;
   double glb_run = 0.0;  // running best lower bound on the score (same value in every thread)
-  if constexpr (FAST) {
+  {
     // best single atom of each dictionary (first index on ties): they stand for every pair whose
-    // optimum has one active atom (mf_utils.py:357-379); phase 3 expands the winner's family exactly
+    // optimum has one active atom (mf_utils.py:357-379); phase 3 expands the winner's family exactly.
+    // (Both paths: ranking the single-active cases inside the scan floods the short list with one entry per
+    // (lane,row) slot whenever one atom suffices -- 513 entries > MFX_MAXC on a 0.14 % / 99.86 % voxel.)
     double* s_bs = s_red;            // [2][8] per-wave bests
     int* s_bn = (int*)(s_red + 16);  // [2][8]
 #pragma unroll
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     for (int k = 0; k < 2; ++k) {
       double s = s_bs[k * 8];
       int n = s_bn[k * 8];
-      for (int w = 1; w < 8; ++w) {
+      for (int w = 1; w < NW; ++w) {
         const double s2 = s_bs[k * 8 + w];
         const int n2 = s_bn[k * 8 + w];
         if (s2 > s || (s2 == s && n2 < n)) { s = s2; n = n2; }
@@ -400,8 +404,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
         // (numerically) collinear atom pairs carry no two-atom information: rank them by their
         // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
         const bool both = (d1 > 0.0) & (d2 > 0.0) & (Det > MFX_DET_REL * pd);
-        const double smax = fmax(s1r[r], s2);
-        double p = both ? num : smax;
+        double p = both ? num : 0.0;   // single-active cases: the two best single atoms, see phase 1
         const double q = both ? Det : 1.0;
         p = (colok & rowok[r]) ? p : 0.0;
         const bool better = p * bq[r] > bp[r] * q;

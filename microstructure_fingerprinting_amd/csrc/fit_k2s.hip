@@ -51,7 +51,8 @@ __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo)
   lo = (_Float16)((f - (float)hi) * 2048.0f);
 }
 
-template <int KS>
+// BR: the protocol has G-bracketed rows (screening through the plan's virtual shells, exact stage as mfx_eval_br)
+template <int KS, bool BR = false>
 __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   constexpr int WG = 512, NW = 8;
   constexpr int MP = KS * 16;  // padded measurement count
@@ -81,6 +82,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
   float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
   float* s_yf = s_Zf + 2 * NP;                     // [MP] FP32 copy of y (ranking statistics)
+  // bracketed protocols: exact-stage descriptors of the upper shell, and separate screening row offsets
+  double* s_t1 = (double*)(s_yf + MP);             // [2][MP]
+  double* s_tG = s_t1 + (BR ? 2 * MP : 0);         // [MP]
+  double* s_dG = s_tG + (BR ? MP : 0);             // [MP]
+  int* s_r1 = (int*)(s_dG + (BR ? MP : 0));        // [2][MP] upper-shell knot row * ldn, or -1
+  int* s_rs = BR ? s_r1 + 2 * MP : s_r0;           // [2][MP] row offsets used by the screening passes
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -94,7 +101,26 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
     s_r0[idx] = rd.r0 * ldn;
     s_t0[idx] = rd.t0;
-    s_t0f[idx] = (float)rd.t0;
+    if constexpr (!BR) {
+      s_t0f[idx] = (float)rd.t0;
+    } else {
+      s_r1[idx] = rd.r1 < 0 ? -1 : rd.r1 * ldn;
+      s_t1[idx] = rd.t1;
+      if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
+      // screening descriptor: the row's single (possibly virtual) shell of the plan's screening view
+      int rs = a.T.P;
+      double ts = 0.0;
+      if (m < M) {
+        const int sg = a.P.s_scr[m], st = a.P.offs[2 * sg], cn = a.P.offs[2 * sg + 1];
+        const double u = mfx_absdot(a.P.g + 3 * m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
+        int j = mfx_searchsorted_left(a.P.xs + st, cn, u);
+        j = j < 1 ? 1 : (j > cn - 1 ? cn - 1 : j);
+        rs = st + j - 1;
+        ts = u - a.P.xs[rs];
+      }
+      s_rs[idx] = rs * ldn;
+      s_t0f[idx] = (float)ts;
+    }
   }
   if (tid == 0) { s_cnt[0] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
   __syncthreads();
@@ -102,14 +128,23 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   // table entry (row offset ro, atom n) through a 32-bit element offset: SGPR base + VGPR offset addressing
   auto tab_at = [&](int ro, int n) -> double2 { return *(const double2*)((const char*)tab + ((unsigned)(ro + n) << 4)); };
   // the FP32 copy of the table feeds everything that only RANKS pairs (half the L2 -> CU bytes)
-  const float2* __restrict__ tab32 = a.T.tab32;
+  const float2* __restrict__ tab32 = a.P.tab32s;   // == a.T.tab32 unless the plan has virtual shells
   auto tab32_at = [&](int ro, int n) -> float2 { return *(const float2*)((const char*)tab32 + ((unsigned)(ro + n) << 3)); };
   // two adjacent atoms (n even) in one 16-byte load: {ylo_n, slope_n, ylo_n+1, slope_n+1}
   auto tab32x2_at = [&](int ro, int n) -> f32x4 { return *(const f32x4*)((const char*)tab32 + ((unsigned)(ro + n) << 3)); };
   // exact-arithmetic rotated dictionary entry: slope * t + y_lo, separate mul and add (mfx_eval)
   auto elem = [&](int k, int m, int n) -> double {
     const double2 e = tab_at(s_r0[k * MP + m], n);
-    return e.y * s_t0[k * MP + m] + e.x;
+    const double v0 = e.y * s_t0[k * MP + m] + e.x;
+    if constexpr (BR) {   // linear interpolation in G between the two shell values, mf_utils.py:1950-1955 (mfx_eval_br)
+      const int r1 = s_r1[k * MP + m];
+      if (r1 < 0) return v0;
+      const double2 f = tab_at(r1, n);
+      const double v1 = f.y * s_t1[k * MP + m] + f.x;
+      const double sl = (v1 - v0) / s_dG[m];
+      return sl * s_tG[m] + v0;
+    }
+    return v0;
   };
 
   MFX_STAMP(1);
@@ -148,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (wact[q]) {   // wave-uniform
-            const i32x4 r = *(const i32x4*)(s_r0 + kq[q] * MP + m4);
+            const i32x4 r = *(const i32x4*)(s_rs + kq[q] * MP + m4);
             const f32x4 t = *(const f32x4*)(s_t0f + kq[q] * MP + m4);
             const int ncl = min(nq[q], ldn - 2);   // ldn is even: the pair stays inside the row
 #pragma unroll
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         constexpr int ks = decltype(kc)::value;
         float2 d[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = tab32_at(s_r0[16 * ks + 8 * lh + j], nn);
+        for (int j = 0; j < 8; ++j) d[j] = tab32_at(s_rs[16 * ks + 8 * lh + j], nn);
         h8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -367,12 +402,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
         float2 d[2][8];   // table entries of k-step ks (in use) and ks+1 (in flight)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[0][j] = tab32_at(s_r0[MP + 8 * lh + j], nn);
+        for (int j = 0; j < 8; ++j) d[0][j] = tab32_at(s_rs[MP + 8 * lh + j], nn);
         mfx_static_for<0, KS>([&](auto kc) {
           constexpr int ks = decltype(kc)::value;
           if constexpr (ks + 1 < KS) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[(ks + 1) & 1][j] = tab32_at(s_r0[MP + 16 * (ks + 1) + 8 * lh + j], nn);
+            for (int j = 0; j < 8; ++j) d[(ks + 1) & 1][j] = tab32_at(s_rs[MP + 16 * (ks + 1) + 8 * lh + j], nn);
           }
           h8 bh, bl;
 #pragma unroll
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       const int nn = min(ch * 32 + 2 * (tg & 15), ldn - 2);
       const int q = gact ? gq : KS * grp;     // idle threads repeat a valid address, gen_store skips them
 #pragma unroll
-      for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_r0[MP + 8 * q + e], nn);
+      for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_rs[MP + 8 * q + e], nn);
     };
     auto gen_store = [&](int ch) {
       if (gact) {

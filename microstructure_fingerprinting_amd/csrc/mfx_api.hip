@@ -65,7 +65,7 @@ extern "C" double mfx_last_kernel_ms(void) {
 struct mfx_tables {
   int device = 0;
   TablesDev d{};
-  std::vector<double> h_x, h_G;
+  std::vector<double> h_x, h_G, h_Y;   // h_Y [P x N]: kept for the per-plan virtual shells of bracketed rows
   std::vector<int> h_off;
   void* dx = nullptr;
   void* doff = nullptr;
@@ -82,6 +82,11 @@ struct mfx_plan {
   void* dshi = nullptr;
   void* dtG = nullptr;
   void* ddG = nullptr;
+  // screening view (only allocated when the protocol has G-bracketed rows)
+  void* dtab32s = nullptr;
+  void* dxs = nullptr;
+  void* doffs = nullptr;
+  void* dsscr = nullptr;
 };
 
 static int require_device(int device) {
@@ -119,6 +124,7 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
   t->device = device;
   t->h_x.assign(knots_x, knots_x + P);
   t->h_G.assign(G_un, G_un + S);
+  t->h_Y.assign(knots_Y, knots_Y + (size_t)P * N);
   t->h_off.assign(shell_off, shell_off + S + 1);
   HIPCHK(hipMalloc(&t->dx, sizeof(double) * P));
   HIPCHK(hipMalloc(&t->doff, sizeof(int) * (S + 1)));
@@ -183,6 +189,81 @@ static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g,
   p->d.dG = (const double*)p->ddG;
   p->d.any_bracket = 0;
   for (int m = 0; m < M; ++m) p->d.any_bracket |= (shi[m] >= 0);
+  // ---- screening view
+  p->d.tab32s = t->d.tab32; p->d.xs = nullptr; p->d.offs = nullptr; p->d.s_scr = nullptr;
+  if (p->d.any_bracket) {
+    const int S = t->d.S, N = t->d.N, ldn = t->d.ldn, P = t->d.P;
+    const double* X = t->h_x.data();
+    const double* Y = t->h_Y.data();
+    const int* off = t->h_off.data();
+    // SciPy interp1d._call_linear on shell s at u, atom n (same clipping as mfx_shell_locate)
+    auto interp = [&](int s, double u, int n) {
+      const int o = off[s], Ps = off[s + 1] - o;
+      int j = (int)(std::lower_bound(X + o, X + o + Ps, u) - (X + o));
+      j = j < 1 ? 1 : (j > Ps - 1 ? Ps - 1 : j);
+      const int r = o + j - 1;
+      const double sl = (Y[(size_t)(r + 1) * N + n] - Y[(size_t)r * N + n]) / (X[r + 1] - X[r]);
+      return sl * (u - X[r]) + Y[(size_t)r * N + n];
+    };
+    struct VS { int lo, hi; double w; };
+    std::vector<VS> vs;
+    std::vector<int> sscr(M);
+    std::vector<double> xs(t->h_x);      // knot value per table row
+    xs.push_back(0.0);                   // row P (zero row) has no knot
+    std::vector<int> offs;               // [2 x n_shells]: first row, knot count
+    for (int s = 0; s < S; ++s) { offs.push_back(off[s]); offs.push_back(off[s + 1] - off[s]); }
+    std::vector<float2> tabs((size_t)(P + 1) * ldn, float2{0.0f, 0.0f});
+    for (int r = 0; r < P; ++r)
+      for (int n = 0; n < N; ++n) {
+        const int s = (int)(std::upper_bound(off, off + S + 1, r) - off) - 1;
+        const bool last = (r == off[s + 1] - 1);
+        const double sl = last ? 0.0 : (Y[(size_t)(r + 1) * N + n] - Y[(size_t)r * N + n]) / (X[r + 1] - X[r]);
+        tabs[(size_t)r * ldn + n] = float2{(float)Y[(size_t)r * N + n], (float)sl};
+      }
+    for (int m = 0; m < M; ++m) {
+      if (shi[m] < 0) { sscr[m] = slo[m]; continue; }
+      const double w = tG[m] / dG[m];
+      int v = -1;
+      for (size_t q = 0; q < vs.size(); ++q)
+        if (vs[q].lo == slo[m] && vs[q].hi == shi[m] && vs[q].w == w) { v = (int)q; break; }
+      if (v < 0) {
+        v = (int)vs.size();
+        vs.push_back(VS{slo[m], shi[m], w});
+        std::vector<double> xv(X + off[slo[m]], X + off[slo[m] + 1]);
+        xv.insert(xv.end(), X + off[shi[m]], X + off[shi[m] + 1]);
+        std::sort(xv.begin(), xv.end());
+        xv.erase(std::unique(xv.begin(), xv.end()), xv.end());
+        const int K = (int)xv.size();
+        std::vector<double> yv((size_t)K * N);
+        for (int k = 0; k < K; ++k)
+          for (int n = 0; n < N; ++n) {
+            const double v0 = interp(slo[m], xv[k], n), v1 = interp(shi[m], xv[k], n);
+            yv[(size_t)k * N + n] = v0 + (v1 - v0) * w;
+          }
+        const size_t base = tabs.size() / ldn;   // first row of this virtual shell
+        tabs.resize(tabs.size() + (size_t)K * ldn, float2{0.0f, 0.0f});
+        for (int k = 0; k < K; ++k)
+          for (int n = 0; n < N; ++n) {
+            const double sl = (k == K - 1) ? 0.0 : (yv[(size_t)(k + 1) * N + n] - yv[(size_t)k * N + n]) / (xv[k + 1] - xv[k]);
+            tabs[(base + k) * ldn + n] = float2{(float)yv[(size_t)k * N + n], (float)sl};
+          }
+        xs.insert(xs.end(), xv.begin(), xv.end());   // xs.size() == base before: knot index == table row
+        offs.push_back((int)base);
+        offs.push_back(K);
+      }
+      sscr[m] = t->d.S + v;
+    }
+    HIPCHK(hipMalloc(&p->dtab32s, sizeof(float2) * tabs.size()));
+    HIPCHK(hipMalloc(&p->dxs, sizeof(double) * xs.size()));
+    HIPCHK(hipMalloc(&p->doffs, sizeof(int) * offs.size()));
+    HIPCHK(hipMalloc(&p->dsscr, sizeof(int) * M));
+    HIPCHK(hipMemcpy(p->dtab32s, tabs.data(), sizeof(float2) * tabs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dxs, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->doffs, offs.data(), sizeof(int) * offs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dsscr, sscr.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+    p->d.tab32s = (const float2*)p->dtab32s; p->d.xs = (const double*)p->dxs;
+    p->d.offs = (const int*)p->doffs; p->d.s_scr = (const int*)p->dsscr;
+  }
   *out = p;
   return MFX_OK;
 }
@@ -235,6 +316,7 @@ extern "C" void mfx_plan_destroy(mfx_plan* p) {
   (void)hipFree(p->dshi);
   (void)hipFree(p->dtG);
   (void)hipFree(p->ddG);
+  (void)hipFree(p->dtab32s); (void)hipFree(p->dxs); (void)hipFree(p->doffs); (void)hipFree(p->dsscr);
   delete p;
 }
 
@@ -288,19 +370,20 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 }
 
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
-static size_t k2s_lds_bytes(int KS, int N) {
+static size_t k2s_lds_bytes(int KS, int N, bool bracket = true) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (2 * NP) + 4 * MP;
+  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (2 * NP) + 4 * MP +
+         (bracket ? 48 * MP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
 static thread_local int g_last_fallback = 0;
 extern "C" int mfx_debug_last_fallback_count(void) { return g_last_fallback; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { g_k2_screen = enabled ? 1 : 0; }
 
-template <int KS>
+template <int KS, bool BR>
 static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
-  const size_t lds = k2s_lds_bytes(KS, a.T.N);
-  auto kern = mfx_fit_k2s_kernel<KS>;
+  const size_t lds = k2s_lds_bytes(KS, a.T.N, BR);
+  auto kern = mfx_fit_k2s_kernel<KS, BR>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int* fb = nullptr;   // [0] count, [1..] voxel list
   HIPCHK(hipMallocAsync((void**)&fb, sizeof(int) * ((size_t)nvox + 1), st));
@@ -337,10 +420,15 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
 static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
   const int M = a.P.M;
-  if (g_k2_screen && !a.P.any_bracket && M <= 208 && k2s_lds_bytes(13, a.T.N) <= 160 * 1024) {
-    if (M <= 64) return launch_k2s_t<4>(a, nvox, st);
-    if (M <= 128) return launch_k2s_t<8>(a, nvox, st);
-    return launch_k2s_t<13>(a, nvox, st);
+  if (g_k2_screen && M <= 208 && k2s_lds_bytes(13, a.T.N) <= 160 * 1024) {
+    if (a.P.any_bracket) {
+      if (M <= 64) return launch_k2s_t<4, true>(a, nvox, st);
+      if (M <= 128) return launch_k2s_t<8, true>(a, nvox, st);
+      return launch_k2s_t<13, true>(a, nvox, st);
+    }
+    if (M <= 64) return launch_k2s_t<4, false>(a, nvox, st);
+    if (M <= 128) return launch_k2s_t<8, false>(a, nvox, st);
+    return launch_k2s_t<13, false>(a, nvox, st);
   }
   return launch_k2_f64(a, nvox, st);
 }

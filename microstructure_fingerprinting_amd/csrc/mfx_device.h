@@ -31,6 +31,14 @@ struct PlanDev {
   const double* tG;  // [M]
   const double* dG;  // [M]
   int any_bracket;
+  // Screening view of the protocol (fit_k2s.hip only ranks with it; exact arithmetic never uses it): every row maps
+  // to ONE knot table.  Exact-shell rows use the table's own shells; a G-bracketed row uses a "virtual shell" built
+  // once per plan: the blend (1-w) shell_lo + w shell_hi, w = (G-G_lo)/(G_hi-G_lo), which is itself piecewise linear
+  // in u on the union of the two shells' knots.  Without bracketed rows tab32s aliases TablesDev::tab32 and the other three are unused.
+  const float2* tab32s;  // [(Ps_rows) x ldn] FP32 {ylo, slope}; rows 0..P as TablesDev::tab32 (row P zero), then virtual rows
+  const double* xs;      // knot value per row of tab32s (bracketed plans only)
+  const int* offs;       // [n_shells][2] first row, knot count of the table shells followed by the virtual shells
+  const int* s_scr;      // [M] shell of the row in (xs, offs)
 };
 
 // per-(direction,row) evaluation descriptor: which knot interval, and the offset inside it

@@ -233,6 +233,60 @@ def test_k2_screening_kernel_equals_fp64_kernel_c2():
     assert np.max(res[0][1200:1300, 5]) < 1e-12 * 500 ** 2
 
 
+def test_k2_screening_kernel_bracketed_protocol():
+    """Protocol whose gradient strengths fall BETWEEN the dictionary's shells (UKBB-like: a handful of distinct G values,
+    mf_utils.py:1827-1839): the screening kernel ranks through the plan's virtual shells (blend of the two bracketing
+    shells on the union of their knots) and evaluates the short list with the reference's bracketing arithmetic.
+    8 000 voxels, 782 atoms: bit-identical to the FP64 kernel, and equal to the oracle on a sample."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    sch_ms, dic, rng = synth.make_model("C2")
+    ms = mfu.init_PGSE_multishell_interp(dic, sch_ms, Z)
+    Gs = ms["Gms_un"]
+    sch = sch_ms[rng.permutation(sch_ms.shape[0])[:150]].copy()       # subject protocol: 150 of the 200 directions
+    nz = np.where(sch[:, 3] > 0)[0]
+    between = [0.3 * Gs[1] + 0.7 * Gs[2], 0.55 * Gs[2] + 0.45 * Gs[3], 0.9 * Gs[2] + 0.1 * Gs[3], 0.5 * (Gs[1] + Gs[2])]
+    sch[nz[::2], 3] = rng.choice(between, size=nz[::2].size)          # half of the rows bracketed, 4 distinct G
+    plan = ms.plan_for(sch)
+    V, N, M = 8000, ms.num_subs, sch.shape[0]
+    dev = torch.device("cuda", 0)
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    atoms = rng.integers(0, N, (V, 2)).astype(np.int32)
+    nu = rng.dirichlet(np.ones(2), V)
+    d_pk = torch.from_numpy(peaks).to(dev)
+    d_Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
+    for k in range(2):
+        col = engine.rotate_columns_dev(plan, d_pk[:, 3 * k:3 * k + 3].contiguous(), torch.from_numpy(atoms[:, k].copy()).to(dev))
+        d_Y += 500.0 * torch.from_numpy(nu[:, k:k + 1].copy()).to(dev) * col
+    d_Y += torch.from_numpy(rng.normal(0, 500 / 30.0, (V, M))).to(dev)
+    lib = L.lib()
+    res = []
+    try:
+        for screen in (1, 0):
+            lib.mfx_debug_set_k2_screen(screen)
+            out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
+            L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_pk.data_ptr(), 2, 0, 0, None, None, 0, V,
+                                          out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            torch.cuda.synchronize(dev)
+            if screen:
+                nfb = lib.mfx_debug_last_fallback_count()
+            res.append(out.cpu().numpy())
+    finally:
+        lib.mfx_debug_set_k2_screen(1)
+    bad = np.where(np.any(res[0] != res[1], axis=1))[0]
+    assert bad.size == 0, "screening kernel differs from the FP64 kernel in voxels %s" % bad[:10]
+    assert nfb < 0.02 * V
+    ns = 6
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    z = np.zeros(ns, bool)
+    ref = orc.fit_batch(T, sch, d_Y[:ns].cpu().numpy(), np.full(ns, 2), z, z, peaks[:ns], 2, False, False, None, None, 0,
+                        nthreads=8)
+    _check(res[0][:ns], ref, 2)
+
+
 def test_bad_direction_raises():
     from microstructure_fingerprinting_amd import engine, synth
     from microstructure_fingerprinting_amd import mf_utils as mfu
