@@ -136,6 +136,9 @@ void mfx_debug_set_stamps(void* dev_ptr);
 int mfx_debug_last_fallback_count(void);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
+/* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs
+ * (default and maximum 256; 0 forces that pass for every voxel -- used by the tests to cover it). */
+void mfx_debug_set_k2_maxc(int maxc);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ struct FitK2Args {
   unsigned long long* stamps;  // diagnostic builds only: [gridDim.x][16] s_memtime stamps (null otherwise)
   int* fb_count;        // screening kernel (fit_k2s.hip) only: number of voxels handed back to the FP64 kernel ...
   int* fb_list;         // ... and their voxel indices
+  int maxc;             // FP64 kernel: short-list size beyond which the exhaustive exact pass runs (MFX_MAXC; tests lower it)
 };
 
 #ifdef MFX_STAMPS
@@ -538,8 +539,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     }
     __syncthreads();
   };
-  int ncand = s_cnt[0];
-  ncand = ncand > MFX_MAXC ? MFX_MAXC : ncand;
+  const int nappend = s_cnt[0];
+  const int ncand = nappend > MFX_MAXC ? MFX_MAXC : nappend;
   __syncthreads();   // everyone has read s_cnt / is done with the B buffers
   if (tid == 0) {    // mf_utils.py:327, 382: start from min_obj = y_sq at pair (0,0) with w = 0, strict '<'
     s_win[0] = y_sq; s_win[1] = 0.0; s_win[2] = 0.0; ((long*)s_win)[3] = -1;
@@ -547,9 +548,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
   {
     double res = INFINITY, w0 = 0.0, w1 = 0.0;
     long idx = -1;
-    if (tid < ncand && s_cand[tid].score >= glb_run) {
-      exact_pair(s_cand[tid].i, s_cand[tid].j, w0, w1, res);
-      idx = (long)s_cand[tid].i * N + s_cand[tid].j;
+    if (nappend <= a.maxc) {
+      if (tid < ncand && s_cand[tid].score >= glb_run) {
+        exact_pair(s_cand[tid].i, s_cand[tid].j, w0, w1, res);
+        idx = (long)s_cand[tid].i * N + s_cand[tid].j;
+      }
+    } else {
+      // The short list overflowed (more than MFX_MAXC slot bests within rounding distance of the optimum: massive
+      // near-ties): entries were dropped, so nothing above can be trusted.  Last resort, exact by construction:
+      // every pair through the reference arithmetic (milliseconds for this voxel; no test or benchmark voxel gets here).
+      const long npairs = (long)N * N;
+      for (long pr = tid; pr < npairs; pr += WG) {
+        double r, u0, u1;
+        exact_pair((int)(pr / N), (int)(pr % N), u0, u1, r);
+        if (r < res || (r == res && pr < idx)) { res = r; idx = pr; w0 = u0; w1 = u1; }
+      }
     }
     block_argmin(res, idx, w0, w1);
   }

@@ -333,6 +333,8 @@ static size_t k2_lds_bytes(int ksteps, bool bracket, int NP, int tiles, int nbuf
 static unsigned long long* g_stamps = nullptr;
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
+static int g_k2_maxc = MFX_MAXC;
+extern "C" void mfx_debug_set_k2_maxc(int maxc) { g_k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
 
 template <int KSTEPS, bool BRACKET, bool PIPE = true, int NW = 8, int TILES = 2, int NBUF = 2>
 static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
@@ -348,6 +350,7 @@ static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
   }
   FitK2Args aa = a;
   aa.stamps = g_stamps;
+  aa.maxc = g_k2_maxc;
   hipLaunchKernelGGL(kern, dim3(nvox), dim3(NW * 64), lds, st, aa);
   HIPCHK(hipGetLastError());
   if (g_profiling) {

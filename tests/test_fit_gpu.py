@@ -287,6 +287,40 @@ def test_k2_screening_kernel_bracketed_protocol():
     _check(res[0][:ns], ref, 2)
 
 
+def test_k2_fp64_kernel_exhaustive_last_resort():
+    """The FP64 kernel's last resort when its short list overflows (every pair through the reference arithmetic),
+    forced for every voxel by lowering the overflow threshold to 0: still the oracle's answer, exact-G and bracketed."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    sch_ms = synth.make_scheme(rng, 2, [1000, 2000, 3000], [20, 20, 20])
+    dic = synth.make_dictionary(rng, sch_ms, 48)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch_ms, Z)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    lib = L.lib()
+    try:
+        lib.mfx_debug_set_k2_screen(0)
+        lib.mfx_debug_set_k2_maxc(0)
+        for bracket in (False, True):
+            sch = sch_ms.copy()
+            if bracket:
+                nz = np.where(sch[:, 3] > 0)[0]
+                Gs = ms["Gms_un"]
+                sch[nz[::3], 3] = 0.5 * (Gs[1] + Gs[2])
+            V = 12
+            peaks, Y, _, _ = synth.make_voxels(rng, V, 2, lambda d: np.stack([orc.interp(sch, x, T) for x in d]), 48)
+            Y[0] = 300 * orc.interp(sch, peaks[0, :3], T)[:, 7]            # one atom suffices: massive near-ties
+            z = np.zeros(V, bool)
+            ref = orc.fit_batch(T, sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0)
+            got = engine.fit_batch(ms.plan_for(sch), Y, np.full(V, 2), None, None, peaks, 2, False, False)
+            _check(got, ref, 2)
+    finally:
+        lib.mfx_debug_set_k2_screen(1)
+        lib.mfx_debug_set_k2_maxc(-1)
+
+
 def test_bad_direction_raises():
     from microstructure_fingerprinting_amd import engine, synth
     from microstructure_fingerprinting_amd import mf_utils as mfu
