@@ -1,7 +1,7 @@
-// fit_k2s.hip -- two-fascicle voxels, exact-G protocols: split-FP16 MFMA SCREENING of all atom pairs
-// followed by the exact FP64 evaluation of the short list.  Same inputs, outputs and results as
-// mfx_fit_k2_kernel (fit_k2.hip), which stays the path for G-bracketed / long protocols and the
-// fallback for the rare voxel whose short list overflows.
+// fit_k2s.hip -- two-fascicle voxels, protocols of up to 208 measurements (exact-G or G-bracketed rows):
+// split-FP16 MFMA SCREENING of all atom pairs followed by the exact FP64 evaluation of the short list.
+// Same inputs, outputs and results as mfx_fit_k2_kernel (fit_k2.hip), which stays the path for longer
+// protocols and the fallback for the rare voxel whose short list overflows.
 //
 // Why: the 2*N1*N2*M cross-Gram of solve_exhaustive_posweights_2 (mf_utils.py:307-325) only RANKS the
 // pairs; the reference's answer is decided by the few pairs within rounding distance of the best one.
@@ -21,7 +21,11 @@
 //
 // Structure: one 512-thread workgroup per voxel, 8 waves = 8 row tiles of 32 atoms of D1 per round; a
 // wave keeps its tile (hi and lo, K = 16*KS) in 8*KS VGPRs; D2 is generated 32 atoms at a time into a
-// double-buffered LDS image laid out in MFMA fragment order (ds_read_b128, conflict-free).
+// double-buffered LDS image laid out in MFMA fragment order (ds_read_b128, conflict-free), waves 0-3 and
+// 4-7 alternating between the MFMAs of a chunk and VALU work (pair screen + generation) half-step by
+// half-step; a last round with one row tile left is shared by all waves.  Everything that only ranks reads
+// an FP32 copy of the table, two adjacent atoms per 16-byte load (the vector-memory pipe, not the matrix
+// pipe, is what this kernel saturates next to VALU issue: DESIGN.md 4.0/4.1).
 #pragma once
 #include "fit_k2.hip"
 
@@ -39,6 +43,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // bit pattern of max(x, +0): non-negative doubles order like unsigned integers (LDS atomicMax)
 __device__ __forceinline__ unsigned long long mfx_nonneg_bits(double x) {
   return (unsigned long long)__double_as_longlong(x > 0.0 ? x : 0.0);
+}
+
+// value of lane `l` (compile-time constant) in every lane: v_readlane_b32 x 2, no ds_bpermute index arithmetic
+__device__ __forceinline__ double mfx_readlane_f64(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo) {
@@ -434,7 +446,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // half-step.  Group g multiplies chunk c in half-step 2c+g and screens it in half-step 2c+g+1.
     // Chunk c lives in LDS buffer c&1: it is read in half-steps 2c, 2c+1 and written in 2c-2 (group 1's half)
     // and 2c-1 (group 0's half), i.e. while buffer (c-1)&1 is being read.
-    // Generation item = (atom col, 4 consecutive rows); a group owns 2*KS of the 4*KS row quads of a chunk.
+    // Generation item = (pair of adjacent atoms, the 8 rows of one MFMA fragment); a group owns KS of the 2*KS
+    // fragment row blocks of a chunk, one item per thread.
     // gen_load issues the table loads at the start of the group's MFMA half-step, gen_store converts and writes
     // the FP16 hi/lo fragments in its next VALU half-step (the loads fly behind the MFMAs).
     const int grp = wave >> 2, tg = tid & 255;
@@ -623,7 +636,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll 16
           for (int m = 0; m < M; ++m) acc += pa[m] * pb[m];
         }
-        const double a11 = __shfl(acc, 0), a22 = __shfl(acc, 1), a12 = __shfl(acc, 2), y1 = __shfl(acc, 3), y2 = __shfl(acc, 4);
+        const double a11 = mfx_readlane_f64(acc, 0), a22 = mfx_readlane_f64(acc, 1), a12 = mfx_readlane_f64(acc, 2),
+                     y1 = mfx_readlane_f64(acc, 3), y2 = mfx_readlane_f64(acc, 4);
         double r, u0, u1;
         nnls2_exact(y_sq, a11, a12, a22, y1, y2, u0, u1, r);
         const long ix = (long)i * N + j;

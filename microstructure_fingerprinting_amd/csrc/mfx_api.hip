@@ -388,8 +388,14 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
   const size_t lds = k2s_lds_bytes(KS, a.T.N, BR);
   auto kern = mfx_fit_k2s_kernel<KS, BR>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int* fb = nullptr;   // [0] count, [1..] voxel list
-  HIPCHK(hipMallocAsync((void**)&fb, sizeof(int) * ((size_t)nvox + 1), st));
+  struct StreamMem {   // stream-ordered allocation released on every exit path
+    void* p = nullptr;
+    hipStream_t s;
+    explicit StreamMem(hipStream_t s_) : s(s_) {}
+    ~StreamMem() { if (p) (void)hipFreeAsync(p, s); }
+  } fbm(st);
+  HIPCHK(hipMallocAsync(&fbm.p, sizeof(int) * ((size_t)nvox + 1), st));
+  int* fb = (int*)fbm.p;   // [0] count, [1..] voxel list
   HIPCHK(hipMemsetAsync(fb, 0, sizeof(int), st));
   if (g_profiling) {
     if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
@@ -416,7 +422,6 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
     g_profiling = prof;
   }
   if (g_profiling) { g_ev_launches = 1; g_ev_valid = true; }
-  HIPCHK(hipFreeAsync(fb, st));
   return rc;
 }
 
