@@ -5,11 +5,11 @@
 //
 // Why: the 2*N1*N2*M cross-Gram of solve_exhaustive_posweights_2 (mf_utils.py:307-325) only RANKS the
 // pairs; the reference's answer is decided by the few pairs within rounding distance of the best one.
-// So the Gram is computed here from operands split into two FP16 halves,
-//        a = hi + 2^-11 lo (+ r),  |r| <= 1.25 * 2^-22 |a|,      c~ = hi.hi + 2^-11 (hi.lo + lo.hi)
+// So the Gram is computed here from operands split into two FP16 halves (mfx_split16),
+//        a = hi + lo (+ r),  |r| <= 2^-21 |a|,      c~ = hi.hi + hi.lo + lo.hi
 // on v_mfma_f32_32x32x16_f16 (3 instructions per 32x32x16 block, 32x the FP64 MFMA rate), with unit-norm
 // columns so that c~ is the cosine of the pair up to |c~ - c| <= DC (DC = 1e-5 is >10x the measured
-// maximum, bound: 3.5 * 2^-22 truncation + FP32 accumulation of 13 MFMA steps over sum|a_i b_i| <= 1).
+// maximum, bound: 3 * 2^-21 truncation + FP32 accumulation of 13 MFMA steps over sum|a_i b_i| <= 1).
 // For a pair whose optimum has two positive weights the score S = |y|^2 - residual obeys dS/dc = -2 w1 w2
 // with w1 w2 <= |y|^2 / 2 (c >= 0), so |S(c~) - S(c)| <= DC |y|^2 =: m.  Every pair with S(c~) >= thr is
 // appended to a ring in LDS, thr = (largest S(c~) seen) - 2m, which can only drop pairs that are not the
@@ -53,14 +53,20 @@ __device__ __forceinline__ double mfx_readlane_f64(double v, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Operands are scaled by 2^8 on top of the normalisation (folded into the per-atom scale factor) and split WITHOUT
+// rescaling the low half:  f = hi + lo + r,  hi = f with its mantissa truncated to 10 bits (exact in FP16),
+// lo = fp16(f - hi),  |r| <= 2^-21 |f|.  With |f| <= 256 the low halves sit around 256 * 2^-10 * |a|: normal FP16
+// numbers for all but negligible entries (an FP16 subnormal still resolves 6e-8, i.e. 2e-10 of a column norm),
+// so hi.hi, hi.lo and lo.hi can share ONE FP32 accumulator and c~ = acc * 2^-16.
+#define MFX_S_SCALE 256.0f
+#define MFX_S_UNSCALE 0x1p-16f
 __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo) {
-  // f must be ONE rounded FP32 value for both uses below.  Without this barrier the compiler folds the
-  // producing multiply into v_fma_mixlo_f16 for the subtraction while the stored hi comes from
-  // v_cvt_pk_f16_f32 of the rounded product: the two differ by an FP16 ulp in double-rounding cases and
-  // the pair (hi, lo) then misses f by 2^-11 |f| (seen as rare 1e-5 |y|^2 screening errors).
+  // f must be ONE rounded FP32 value for both uses below (the compiler may otherwise fold the producing multiply
+  // into a mixed-precision FMA for one use and not for the other: the halves then miss f by an FP16 ulp)
   asm("" : "+v"(f));   // not volatile: an opaque value, free to schedule
-  hi = (_Float16)f;
-  lo = (_Float16)((f - (float)hi) * 2048.0f);
+  const float h = __uint_as_float(__float_as_uint(f) & 0xffffe000u);
+  hi = (_Float16)h;
+  lo = (_Float16)(f - h);
 }
 
 // BR: the protocol has G-bracketed rows (screening through the plan's virtual shells, exact stage as mfx_eval_br)
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     h8 afh[KS], afl[KS];
     {
       const int n = rtc * 32 + lr;
-      const float asc = rt_valid ? (float)s_I1[n] : 0.0f;
+      const float asc = rt_valid ? (float)s_I1[n] * MFX_S_SCALE : 0.0f;
       const int nn = min(n, ldn - 1);
       mfx_static_for<0, KS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 
     // pair screen of one 32x32 accumulator tile against column tile ct (used by the LDS sweep and by the tail round)
     double thr = 0.0;
-    auto scan_tile = [&](const f32x16& acc_h, const f32x16& acc_x, int ct) {
+    auto scan_tile = [&](const f32x16& acc, int ct) {
       const int j = ct * 32 + lr;
       // ---- pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr.
       // Fast pass in FP32, branch-free: per pair the value
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         for (int u = 0; u < 4; ++u) {
           const int g = 4 * q + u;
           const float z1 = z1q[u];
-          const float c = fmaf(acc_x[g], 0x1p-11f, acc_h[g]);
+          const float c = acc[g] * MFX_S_UNSCALE;
           const float e1 = fmaf(-c, z2f, z1);
           const float e2 = fmaf(-c, z1, z2f);
           const float den = fmaf(-c, c, 1.0f);
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * q + gg;
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            const double c = fma((double)acc_x[g], 0x1p-11, (double)acc_h[g]);
+            const double c = (double)acc[g] * (double)MFX_S_UNSCALE;
             const double z1 = s_Z1[i];
             const double e1 = fma(-c, z2, z1);
             const double e2 = fma(-c, z1, z2);
@@ -407,11 +413,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       thr = __longlong_as_double((long long)s_thr[0]);
       for (int ct = wave; ct < ntiles; ct += NW) {
         const int n = ct * 32 + lr;
-        const float bsc = (float)s_I2[n];
+        const float bsc = (float)s_I2[n] * MFX_S_SCALE;
         const int nn = min(n, ldn - 1);
-        f32x16 acc_h, acc_x;
+        f32x16 acc;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
         float2 d[2][8];   // table entries of k-step ks (in use) and ks+1 (in flight)
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[0][j] = tab32_at(s_rs[MP + 8 * lh + j], nn);
@@ -428,12 +434,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x) * bsc, x, y);
             bh[j] = x; bl[j] = y;
           }
-          acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc_h, 0, 0, 0);
-          acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc_x, 0, 0, 0);
-          acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc_x, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         });
-        scan_tile(acc_h, acc_x, ct);
+        scan_tile(acc, ct);
       }
       __syncthreads();   // all appends of the round are in the ring
       continue;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     auto gen_store = [&](int ch) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
-        const float sc0 = (float)s_I2[ch * 32 + c0], sc1 = (float)s_I2[ch * 32 + c0 + 1];
+        const float sc0 = (float)s_I2[ch * 32 + c0] * MFX_S_SCALE, sc1 = (float)s_I2[ch * 32 + c0 + 1] * MFX_S_SCALE;
         h8 hi0, lo0, hi1, lo1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -493,9 +499,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     if (round == 0) MFX_STAMP(4);
     thr = __longlong_as_double((long long)s_thr[0]);
 
-    f32x16 acc_h, acc_x;
+    f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+    for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
     for (int hs = 0; hs <= 2 * ntiles; ++hs) {
       if ((hs & 1) == grp) {
         // ---- MFMA half-step: chunk c = (hs - grp) / 2
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           if (c + 1 + grp < ntiles) gen_load(c + 1 + grp);   // consumed in this group's next half-step
           if (rt_valid) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { acc_h[g] = 0.0f; acc_x[g] = 0.0f; }
+            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
             const _Float16* bhp = sBh + (c & 1) * KS * 512 + lane * 8;
             const _Float16* blp = sBl + (c & 1) * KS * 512 + lane * 8;
             h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
@@ -515,9 +521,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
                 bhn = *(const h8*)(bhp + (ks + 1) * 512);
                 bln = *(const h8*)(blp + (ks + 1) * 512);
               }
-              acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc_h, 0, 0, 0);
-              acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc_x, 0, 0, 0);
-              acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc_x, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc, 0, 0, 0);
               bh = bhn; bl = bln;
               __builtin_amdgcn_sched_barrier(0);
             });
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         const int c = (hs - 1 - grp) >> 1;
         if (c >= 0 && c < ntiles) {
           if (c + 1 + grp < ntiles) gen_store(c + 1 + grp);
-          if (rt_valid) scan_tile(acc_h, acc_x, c);
+          if (rt_valid) scan_tile(acc, c);
         }
       }
       __syncthreads();
