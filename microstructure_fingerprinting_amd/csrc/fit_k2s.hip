@@ -53,13 +53,14 @@ __device__ __forceinline__ double mfx_readlane_f64(double v, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Operands are scaled by 2^8 on top of the normalisation (folded into the per-atom scale factor) and split WITHOUT
-// rescaling the low half:  f = hi + lo + r,  hi = f with its mantissa truncated to 10 bits (exact in FP16),
+// The A operand (D1 tile) is normalised and scaled by 2^8 (one per-atom factor); the B operand (D2) is NOT normalised --
+// the FP32 screening table is pre-scaled on the host so that its values are <= 128, and the column's 1/|d2| is folded
+// into the factor that turns an accumulator entry into the cosine (one multiply per pair either way).  Both are split
+// WITHOUT rescaling the low half:  f = hi + lo + r,  hi = f with its mantissa truncated to 10 bits (exact in FP16),
 // lo = fp16(f - hi),  |r| <= 2^-21 |f|.  With |f| <= 256 the low halves sit around 256 * 2^-10 * |a|: normal FP16
 // numbers for all but negligible entries (an FP16 subnormal still resolves 6e-8, i.e. 2e-10 of a column norm),
-// so hi.hi, hi.lo and lo.hi can share ONE FP32 accumulator and c~ = acc * 2^-16.
+// so hi.hi, hi.lo and lo.hi can share ONE FP32 accumulator and c~ = acc * (1/|d2|) * 2^-8.
 #define MFX_S_SCALE 256.0f
-#define MFX_S_UNSCALE 0x1p-16f
 __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo) {
   // f must be ONE rounded FP32 value for both uses below (the compiler may otherwise fold the producing multiply
   // into a mixed-precision FMA for one use and not for the other: the halves then miss f by an FP16 ulp)
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
   float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
-  float* s_yf = s_Zf + 2 * NP;                     // [MP] FP32 copy of y (ranking statistics)
+  float* s_cs = s_Zf + 2 * NP;                     // [NP] (1/|d2|) / 2^8: accumulator -> cosine factor of a D2 column
+  float* s_yf = s_cs + NP;                         // [MP] FP32 copy of y (ranking statistics)
   // bracketed protocols: exact-stage descriptors of the upper shell, and separate screening row offsets
   double* s_t1 = (double*)(s_yf + MP);             // [2][MP]
   double* s_tG = s_t1 + (BR ? 2 * MP : 0);         // [MP]
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             (k ? s_I2 : s_I1)[n] = inv;
             (k ? s_Z2 : s_Z1)[n] = act ? z : -INFINITY;
             s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+            if (k) s_cs[n] = (float)inv * (1.0f / MFX_S_SCALE);
             const double s = z > 0.0 ? z * z : 0.0;
             if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
           }
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       // evaluation error of f, < 1e-6 |y|^2 for |z| <= |y|, |c| <= 1); the maxima of m over the four
       // register groups decide whether the (rare) exact FP64 pass runs for a group.
       thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
-      const float z2f = s_Zf[NP + j];
+      const float z2f = s_Zf[NP + j], csj = s_cs[j];
       const float thrf = (float)thr * (1.0f - 2e-7f);   // rounded down
       float mm[4];
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         for (int u = 0; u < 4; ++u) {
           const int g = 4 * q + u;
           const float z1 = z1q[u];
-          const float c = acc[g] * MFX_S_UNSCALE;
+          const float c = acc[g] * csj;
           const float e1 = fmaf(-c, z2f, z1);
           const float e2 = fmaf(-c, z1, z2f);
           const float den = fmaf(-c, c, 1.0f);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * q + gg;
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            const double c = (double)acc[g] * (double)MFX_S_UNSCALE;
+            const double c = (double)acc[g] * (s_I2[j] * (1.0 / MFX_S_SCALE));
             const double z1 = s_Z1[i];
             const double e1 = fma(-c, z2, z1);
             const double e2 = fma(-c, z1, z2);
@@ -413,7 +416,6 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       thr = __longlong_as_double((long long)s_thr[0]);
       for (int ct = wave; ct < ntiles; ct += NW) {
         const int n = ct * 32 + lr;
-        const float bsc = (float)s_I2[n] * MFX_S_SCALE;
         const int nn = min(n, ldn - 1);
         f32x16 acc;
 #pragma unroll
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             _Float16 x, y;
-            mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x) * bsc, x, y);
+            mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x), x, y);
             bh[j] = x; bl[j] = y;
           }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
@@ -470,15 +472,14 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     auto gen_store = [&](int ch) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
-        const float sc0 = (float)s_I2[ch * 32 + c0] * MFX_S_SCALE, sc1 = (float)s_I2[ch * 32 + c0 + 1] * MFX_S_SCALE;
         h8 hi0, lo0, hi1, lo1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = s_t0f[MP + 8 * gq + e];
           _Float16 x, y;
-          mfx_split16(fmaf(gd[e][1], t, gd[e][0]) * sc0, x, y);
+          mfx_split16(fmaf(gd[e][1], t, gd[e][0]), x, y);
           hi0[e] = x; lo0[e] = y;
-          mfx_split16(fmaf(gd[e][3], t, gd[e][2]) * sc1, x, y);
+          mfx_split16(fmaf(gd[e][3], t, gd[e][2]), x, y);
           hi1[e] = x; lo1[e] = y;
         }
         // fragments of atoms c0, c0+1 are adjacent: 32 contiguous bytes per lane, conflict-free

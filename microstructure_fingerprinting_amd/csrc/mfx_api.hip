@@ -66,6 +66,7 @@ struct mfx_tables {
   int device = 0;
   TablesDev d{};
   std::vector<double> h_x, h_G, h_Y;   // h_Y [P x N]: kept for the per-plan virtual shells of bracketed rows
+  double scr_scale = 1.0;              // power of two baked into the FP32 screening tables (see mfx_tables_create)
   std::vector<int> h_off;
   void* dx = nullptr;
   void* doff = nullptr;
@@ -135,8 +136,15 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
   HIPCHK(hipMemcpy(t->dtab, tab.data(), sizeof(double2) * tab.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(t->dG, G_un, sizeof(double) * S, hipMemcpyHostToDevice));
   {
+    // FP32 screening copy, scaled by a power of two so that the largest table value lies in (64, 128]: the screening
+    // kernel feeds D2 to the FP16 MFMA WITHOUT normalising it (the column norm is applied to the accumulator), so the
+    // raw values must sit comfortably inside the FP16 range whatever units the dictionary uses.  Ranking statistics
+    // (1/|d|, d.y/|d|) are invariant under this scale.
+    double vmax = 0.0;
+    for (size_t q = 0; q < (size_t)P * N; ++q) vmax = std::max(vmax, std::fabs(knots_Y[q]));
+    t->scr_scale = (vmax > 0.0 && std::isfinite(vmax)) ? std::exp2(7.0 - std::ceil(std::log2(vmax))) : 1.0;
     std::vector<float2> tab32(tab.size());
-    for (size_t q = 0; q < tab.size(); ++q) tab32[q] = float2{(float)tab[q].x, (float)tab[q].y};
+    for (size_t q = 0; q < tab.size(); ++q) tab32[q] = float2{(float)(tab[q].x * t->scr_scale), (float)(tab[q].y * t->scr_scale)};
     HIPCHK(hipMalloc(&t->dtab32, sizeof(float2) * tab32.size()));
     HIPCHK(hipMemcpy(t->dtab32, tab32.data(), sizeof(float2) * tab32.size(), hipMemcpyHostToDevice));
   }
@@ -218,7 +226,7 @@ static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g,
         const int s = (int)(std::upper_bound(off, off + S + 1, r) - off) - 1;
         const bool last = (r == off[s + 1] - 1);
         const double sl = last ? 0.0 : (Y[(size_t)(r + 1) * N + n] - Y[(size_t)r * N + n]) / (X[r + 1] - X[r]);
-        tabs[(size_t)r * ldn + n] = float2{(float)Y[(size_t)r * N + n], (float)sl};
+        tabs[(size_t)r * ldn + n] = float2{(float)(Y[(size_t)r * N + n] * t->scr_scale), (float)(sl * t->scr_scale)};
       }
     for (int m = 0; m < M; ++m) {
       if (shi[m] < 0) { sscr[m] = slo[m]; continue; }
@@ -245,7 +253,7 @@ static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g,
         for (int k = 0; k < K; ++k)
           for (int n = 0; n < N; ++n) {
             const double sl = (k == K - 1) ? 0.0 : (yv[(size_t)(k + 1) * N + n] - yv[(size_t)k * N + n]) / (xv[k + 1] - xv[k]);
-            tabs[(base + k) * ldn + n] = float2{(float)yv[(size_t)k * N + n], (float)sl};
+            tabs[(base + k) * ldn + n] = float2{(float)(yv[(size_t)k * N + n] * t->scr_scale), (float)(sl * t->scr_scale)};
           }
         xs.insert(xs.end(), xv.begin(), xv.end());   // xs.size() == base before: knot index == table row
         offs.push_back((int)base);
@@ -375,7 +383,7 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
 static size_t k2s_lds_bytes(int KS, int N, bool bracket = true) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (2 * NP) + 4 * MP +
+  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (3 * NP) + 4 * MP +
          (bracket ? 48 * MP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
