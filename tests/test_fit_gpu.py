@@ -321,6 +321,29 @@ def test_k2_fp64_kernel_exhaustive_last_resort():
         lib.mfx_debug_set_k2_maxc(-1)
 
 
+@pytest.mark.parametrize("unit", [1e4, 1e-5])
+def test_k2_dictionary_units(unit):
+    """The screening kernel feeds D2 to the FP16 matrix pipe un-normalised: whatever units the dictionary is stored in
+    (here x1e4 and x1e-5, signals scaled alike), the host pre-scales the FP32 screening table into the FP16 range and
+    the results still equal the oracle's."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(77)
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000], [30, 30, 30])
+    dic = synth.make_dictionary(rng, sch, 100) * unit
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    V = 32
+    peaks, Y, _, _ = synth.make_voxels(rng, V, 2, lambda d: np.stack([orc.interp(sch, x, T) for x in d]), 100, snr=30.0 / unit)
+    z = np.zeros(V, bool)
+    ref = orc.fit_batch(T, sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0)
+    got = engine.fit_batch(ms.plan_for(sch), Y, np.full(V, 2), None, None, peaks, 2, False, False)
+    ids = slice(3, 5)
+    assert np.array_equal(got[:, ids], ref[:, ids]), "selected atom indices differ"
+    assert np.allclose(got, ref, rtol=RTOL_W, atol=0)
+
+
 def test_bad_direction_raises():
     from microstructure_fingerprinting_amd import engine, synth
     from microstructure_fingerprinting_amd import mf_utils as mfu
