@@ -344,6 +344,57 @@ def test_k2_dictionary_units(unit):
     assert np.allclose(got, ref, rtol=RTOL_W, atol=0)
 
 
+@pytest.mark.parametrize("N,dirs", [(31, [20, 20, 20]), (32, [9, 9, 9]), (33, [40, 41, 42]), (64, [60, 60, 60]), (255, [20, 21, 20]),
+                                    (257, [66, 66, 66]), (288, [30, 30, 30]), (289, [12, 12, 12]), (513, [40, 40, 40]),
+                                    (545, [66, 67, 66]), (800, [33, 33, 33])])
+def test_k2_screening_kernel_shapes(N, dirs):
+    """Tile/round/tail logic of the screening kernel across dictionary sizes (1 round, full rounds, a single leftover
+    row tile shared by all waves: 9, 17 and 25 tiles) and protocol lengths (the KS = 4, 8, 13 instantiations):
+    bit-identical to the FP64 kernel on 256 voxels, equal to the oracle on a few."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000 + N)
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000], dirs)
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    V, M = 256, sch.shape[0]
+    dev = torch.device("cuda", 0)
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    atoms = rng.integers(0, N, (V, 2)).astype(np.int32)
+    nu = rng.dirichlet(np.ones(2), V)
+    nu[:16] = [1.0, 0.0]
+    d_pk = torch.from_numpy(peaks).to(dev)
+    d_Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
+    for k in range(2):
+        col = engine.rotate_columns_dev(plan, d_pk[:, 3 * k:3 * k + 3].contiguous(), torch.from_numpy(atoms[:, k].copy()).to(dev))
+        d_Y += 500.0 * torch.from_numpy(nu[:, k:k + 1].copy()).to(dev) * col
+    d_Y += torch.from_numpy(rng.normal(0, 500 / 30.0, (V, M))).to(dev)
+    lib = L.lib()
+    res = []
+    try:
+        for screen in (1, 0):
+            lib.mfx_debug_set_k2_screen(screen)
+            out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
+            L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_pk.data_ptr(), 2, 0, 0, None, None, 0, V,
+                                          out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            torch.cuda.synchronize(dev)
+            res.append(out.cpu().numpy())
+    finally:
+        lib.mfx_debug_set_k2_screen(1)
+    bad = np.where(np.any(res[0] != res[1], axis=1))[0]
+    assert bad.size == 0, "screening kernel differs from the FP64 kernel in voxels %s" % bad[:10]
+    ns = 4
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    z = np.zeros(ns, bool)
+    ref = orc.fit_batch(T, sch, d_Y[:ns].cpu().numpy(), np.full(ns, 2), z, z, peaks[:ns], 2, False, False, None, None, 0,
+                        nthreads=8)
+    _check(res[0][:ns], ref, 2)
+
+
 def test_bad_direction_raises():
     from microstructure_fingerprinting_amd import engine, synth
     from microstructure_fingerprinting_amd import mf_utils as mfu
