@@ -1,4 +1,4 @@
-// fit_k2s.hip -- two-fascicle voxels, protocols of up to 208 measurements (exact-G or G-bracketed rows):
+// fit_k2s.hip -- two-fascicle voxels, protocols of up to 256 measurements (exact-G or G-bracketed rows):
 // split-FP16 MFMA SCREENING of all atom pairs followed by the exact FP64 evaluation of the short list.
 // Same inputs, outputs and results as mfx_fit_k2_kernel (fit_k2.hip), which stays the path for longer
 // protocols and the fallback for the rare voxel whose short list overflows.

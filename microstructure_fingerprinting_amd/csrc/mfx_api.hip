@@ -436,15 +436,18 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
 static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
   const int M = a.P.M;
-  if (g_k2_screen && M <= 208 && k2s_lds_bytes(13, a.T.N) <= 160 * 1024) {
+  const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
+  if (g_k2_screen && M <= 256 && k2s_lds_bytes(KSm, a.T.N, a.P.any_bracket != 0) <= 160 * 1024) {
     if (a.P.any_bracket) {
-      if (M <= 64) return launch_k2s_t<4, true>(a, nvox, st);
-      if (M <= 128) return launch_k2s_t<8, true>(a, nvox, st);
-      return launch_k2s_t<13, true>(a, nvox, st);
+      if (KSm == 4) return launch_k2s_t<4, true>(a, nvox, st);
+      if (KSm == 8) return launch_k2s_t<8, true>(a, nvox, st);
+      if (KSm == 13) return launch_k2s_t<13, true>(a, nvox, st);
+      return launch_k2s_t<16, true>(a, nvox, st);
     }
-    if (M <= 64) return launch_k2s_t<4, false>(a, nvox, st);
-    if (M <= 128) return launch_k2s_t<8, false>(a, nvox, st);
-    return launch_k2s_t<13, false>(a, nvox, st);
+    if (KSm == 4) return launch_k2s_t<4, false>(a, nvox, st);
+    if (KSm == 8) return launch_k2s_t<8, false>(a, nvox, st);
+    if (KSm == 13) return launch_k2s_t<13, false>(a, nvox, st);
+    return launch_k2s_t<16, false>(a, nvox, st);
   }
   return launch_k2_f64(a, nvox, st);
 }
