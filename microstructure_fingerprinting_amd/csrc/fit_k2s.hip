@@ -100,10 +100,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
   float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
-  float* s_cs = s_Zf + 2 * NP;                     // [NP] (1/|d2|) / 2^8: accumulator -> cosine factor of a D2 column
+  float* s_cs = s_Zf + 2 * NP;                     // [NP] 2^8 |d2|: cosine -> accumulator factor of a D2 column (0: no such atom)
   float* s_yf = s_cs + NP;                         // [MP] FP32 copy of y (ranking statistics)
+  float* s_pq = s_yf + MP;                         // [NW][2][32] pair-screen constants of each wave's 32 rows
   // bracketed protocols: exact-stage descriptors of the upper shell, and separate screening row offsets
-  double* s_t1 = (double*)(s_yf + MP);             // [2][MP]
+  double* s_t1 = (double*)(s_pq + NW * 64);        // [2][MP]
   double* s_tG = s_t1 + (BR ? 2 * MP : 0);         // [MP]
   double* s_dG = s_tG + (BR ? MP : 0);             // [MP]
   int* s_r1 = (int*)(s_dG + (BR ? MP : 0));        // [2][MP] upper-shell knot row * ldn, or -1
@@ -173,7 +174,6 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
   const double mrg = MFX_S_DC * y_sq;        // |S(c~) - S(c)| <= mrg
   const double etol = MFX_S_DC * sqrt(y_sq); // |e(c~) - e(c)| <= etol
-  const float slackf = (float)(4e-6 * y_sq), etolf = (float)(1.05 * etol);   // FP32 fast pass: see the pair screen
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
   {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             (k ? s_I2 : s_I1)[n] = inv;
             (k ? s_Z2 : s_Z1)[n] = act ? z : -INFINITY;
             s_Zf[k * NP + n] = act ? (float)z : -1e30f;
-            if (k) s_cs[n] = (float)inv * (1.0f / MFX_S_SCALE);
+            if (k) s_cs[n] = (act && inv > 0.0) ? (float)(sqrt(a2[q][u]) * (double)MFX_S_SCALE) : 0.0f;
             const double s = z > 0.0 ? z * z : 0.0;
             if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
           }
@@ -331,42 +331,57 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
 
     // pair screen of one 32x32 accumulator tile against column tile ct (used by the LDS sweep and by the tail round)
-    double thr = 0.0;
+    //
+    // Fast pass in FP32, 3 VALU per pair.  With unit atoms at angle phi (c = cos phi), the projection of y on
+    // their plane has squared length S and makes the angles alpha1, alpha2 with them (z_i = sqrt(S) cos alpha_i);
+    // both weights are positive exactly when it lies between the atoms: phi = alpha1 + alpha2.  For any T <= S,
+    // theta_i = acos(min(1, max(z_i, 0) / sqrt(T))) <= alpha_i, hence
+    //     two positive weights and S >= T   ==>   c <= cos(theta1 + theta2) = P1 P2 - Q1 Q2,
+    // P_i = cos theta_i, Q_i = sin theta_i (the other branch of S(c) >= T, c >= cos(theta1 - theta2), has a
+    // non-positive weight).  The test is therefore  c~ - DC <= P1 P2 - Q1 Q2  with T = the running threshold;
+    // a STALE (lower) threshold, P rounded up and Q rounded down only let more pairs through.  In accumulator
+    // units (c = acc / s_cs[j]):  t = P1 (P2 s) - Q1 (Q2 s) - acc,  pass when  max t + DCF s >= 0.  Rows and
+    // columns beyond N get constants that never pass.  Only a register group with a passing pair runs the FP64
+    // criteria below (one out-of-line copy).
+    double thr = 0.0, thr_rows = -1.0;
+    constexpr float DCF = (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
+    auto pq_of = [&](float z, float rth, float& P, float& Q) {
+      P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
+      Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
+    };
     auto scan_tile = [&](const f32x16& acc, int ct) {
       const int j = ct * 32 + lr;
-      // ---- pair screen of the 32x32 tile: row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ch*32 + lr.
-      // Fast pass in FP32, branch-free: per pair the value
-      //     m = min(e1 + etol, e2 + etol, max(f + slack, DENMIN - den, -0.5 - c)),   f = num - thr*den
-      // is >= 0 exactly when the FP64 criteria below COULD hold (slack = 4e-6 |y|^2 covers the FP32
-      // evaluation error of f, < 1e-6 |y|^2 for |z| <= |y|, |c| <= 1); the maxima of m over the four
-      // register groups decide whether the (rare) exact FP64 pass runs for a group.
+      // row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ct*32 + lr
       thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
-      const float z2f = s_Zf[NP + j], csj = s_cs[j];
-      const float thrf = (float)thr * (1.0f - 2e-7f);   // rounded down
+      // 1/sqrt(T), T = thr rounded down, the reciprocal root rounded up (v_rsq_f32: 1 ulp)
+      const float rth = __builtin_amdgcn_rsqf(fmaxf((float)thr * (1.0f - 2e-7f), 1e-30f)) * (1.0f + 4e-7f);
+      float* pqw = s_pq + wave * 64;
+      if (thr > thr_rows) {   // wave-uniform: the threshold rose since this wave's row constants were made
+        thr_rows = thr;
+        if (lane < 32) {
+          const float z1 = s_Zf[rtc * 32 + lane];
+          float P, Q;
+          pq_of(z1, rth, P, Q);
+          const bool ok = z1 > -1e29f;
+          pqw[lane] = ok ? P : -1e18f;
+          pqw[32 + lane] = ok ? Q : 1e18f;
+        }
+      }
+      const float z2f = s_Zf[NP + j], sj = s_cs[j];
+      float P2, Q2;
+      pq_of(z2f, rth, P2, Q2);
+      const bool colok = sj > 0.0f;
+      const float p2 = colok ? P2 * sj : 0.0f, q2 = colok ? Q2 * sj : 1e18f, dcj = colok ? DCF * sj : -1e30f;
       float mm[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float mq = -1.0f;
-        const f32x4 z1q = *(const f32x4*)(s_Zf + rtc * 32 + 8 * q + 4 * lh);   // rows (g&3) + 8q + 4 lh, g = 4q..4q+3
+        const f32x4 p1q = *(const f32x4*)(pqw + 8 * q + 4 * lh);        // rows (g&3) + 8q + 4 lh, g = 4q..4q+3
+        const f32x4 q1q = *(const f32x4*)(pqw + 32 + 8 * q + 4 * lh);
         // plain (not packed) FP32: beside the other wave's MFMAs a v_pk_*_f32 costs several plain ones
+        float t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int g = 4 * q + u;
-          const float z1 = z1q[u];
-          const float c = acc[g] * csj;
-          const float e1 = fmaf(-c, z2f, z1);
-          const float e2 = fmaf(-c, z1, z2f);
-          const float den = fmaf(-c, c, 1.0f);
-          const float t = fmaf(z1, e1, slackf);
-          const float num = fmaf(z2f, e2, t);
-          const float f = fmaf(-thrf, den, num);
-          const float dn = (float)MFX_S_DENMIN - den;
-          const float cn = -0.5f - c;
-          const float ev = fmaxf(fmaxf(f, dn), cn);                        // v_max3_f32
-          const float m = fminf(fminf(e1 + etolf, e2 + etolf), ev);        // v_min3_f32
-          mq = fmaxf(mq, m);
-        }
-        mm[q] = mq;
+        for (int u = 0; u < 4; ++u) t[u] = fmaf(-q1q[u], q2, fmaf(p1q[u], p2, -acc[4 * q + u]));
+        mm[q] = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + dcj;
       }
       if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
         // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
