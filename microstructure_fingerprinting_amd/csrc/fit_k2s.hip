@@ -519,6 +519,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
     for (int hs = 0; hs <= 2 * ntiles; ++hs) {
+#ifdef MFX_STAMPS_HS   // diagnostic builds: start of half-steps 20..35 of round 1 as seen by wave 0 (tools/dev_stamps_hs.py)
+      if (a.stamps && round == 1 && hs >= 20 && hs < 36 && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + hs - 20] = __builtin_amdgcn_s_memtime();
+#endif
       if ((hs & 1) == grp) {
         // ---- MFMA half-step: chunk c = (hs - grp) / 2
         const int c = (hs - grp) >> 1;
