@@ -198,17 +198,34 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         wact[q] = __any((p0 + q < npass) && (nq[q] < N));
         a2[q][0] = a2[q][1] = ay[q][0] = ay[q][1] = 0.0;
       }
-      for (int m4 = 0; m4 < MP; m4 += 4) {
-        const f32x4 yv = *(const f32x4*)(s_yf + m4);
+      // software pipeline over groups of four rows: the 8 table loads of the next group are in flight while this
+      // group is accumulated (the vector-memory pipe and the FP64 VALU work of this pass each take ~40 k cycles per
+      // voxel: un-pipelined they simply add up)
+      int ncl[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ncl[q] = min(nq[q], ldn - 2);   // ldn is even: the pair stays inside the row
+      f32x4 dbuf[2][2][4];
+      auto issue = [&](int m4, auto stc) {
+        constexpr int st = decltype(stc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (wact[q]) {   // wave-uniform
             const i32x4 r = *(const i32x4*)(s_rs + kq[q] * MP + m4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dbuf[st][q][e] = tab32x2_at(r[e], ncl[q]);
+          }
+        }
+      };
+      auto accumulate = [&](int m4, auto stc) {
+        constexpr int st = decltype(stc)::value;
+        const f32x4 yv = *(const f32x4*)(s_yf + m4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (wact[q]) {
             const f32x4 t = *(const f32x4*)(s_t0f + kq[q] * MP + m4);
-            const int ncl = min(nq[q], ldn - 2);   // ldn is even: the pair stays inside the row
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const f32x4 d = tab32x2_at(r[e], ncl);
+              const f32x4 d = dbuf[st][q][e];
               const double d0 = (double)fmaf(d[1], t[e], d[0]), d1 = (double)fmaf(d[3], t[e], d[2]);
               const double ye = (double)yv[e];
               a2[q][0] = fma(d0, d0, a2[q][0]);
@@ -218,6 +235,13 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             }
           }
         }
+      };
+      issue(0, std::integral_constant<int, 0>{});
+      for (int m4 = 0; m4 < MP; m4 += 8) {   // MP is a multiple of 16
+        issue(m4 + 4, std::integral_constant<int, 1>{});
+        accumulate(m4, std::integral_constant<int, 0>{});
+        if (m4 + 8 < MP) issue(m4 + 8, std::integral_constant<int, 0>{});
+        accumulate(m4 + 4, std::integral_constant<int, 1>{});
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
