@@ -139,6 +139,9 @@ void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs
  * (default and maximum 256; 0 forces that pass for every voxel -- used by the tests to cover it). */
 void mfx_debug_set_k2_maxc(int maxc);
+/* Diagnostic: number of short-list ring entries the screening kernel uses (rounded down to a power of two;
+ * default and maximum 2048, <= 0 restores the default) -- the tests lower it to force hand-backs to the FP64 kernel. */
+void mfx_debug_set_k2s_cap(int cap);
 
 #ifdef __cplusplus
 }

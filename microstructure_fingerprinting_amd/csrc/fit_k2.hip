@@ -57,6 +57,7 @@ struct FitK2Args {
   int* fb_count;        // screening kernel (fit_k2s.hip) only: number of voxels handed back to the FP64 kernel ...
   int* fb_list;         // ... and their voxel indices
   int maxc;             // FP64 kernel: short-list size beyond which the exhaustive exact pass runs (MFX_MAXC; tests lower it)
+  int scap;             // screening kernel: ring entries in use (MFX_S_CAP, a power of two; tests lower it to force hand-backs)
 };
 
 #ifdef MFX_STAMPS

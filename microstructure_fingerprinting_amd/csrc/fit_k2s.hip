@@ -36,7 +36,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#define MFX_S_CAP 1024      // ring entries (power of two)
+#define MFX_S_CAP 2048      // ring entries (power of two): two full single-atom families (2 x 782) fit
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
 
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   double* s_dG = s_tG + (BR ? MP : 0);             // [MP]
   int* s_r1 = (int*)(s_dG + (BR ? MP : 0));        // [2][MP] upper-shell knot row * ldn, or -1
   int* s_rs = BR ? s_r1 + 2 * MP : s_r0;           // [2][MP] row offsets used by the screening passes
+  int* s_evl4 = s_r1 + (BR ? 4 * MP : 0);          // [MFX_S_CAP] exact-stage compaction list, KS < 8 only (else inside the B image)
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   // ring append (rare path)
   auto push = [&](double S, int i, int j) {
     const int slot = atomicAdd(&s_cnt[0], 1);
-    const int idx = slot & (MFX_S_CAP - 1);
-    if (slot >= MFX_S_CAP) {   // overwriting: remember the best score that got lost
+    const int idx = slot & (a.scap - 1);
+    if (slot >= a.scap) {   // overwriting: remember the best score that got lost
       const double old = s_cand[idx].score;
       atomicMax(&s_thr[1], mfx_nonneg_bits(fmin(old, 1e300)));
     }
@@ -629,11 +630,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     __syncthreads();
   };
   const int nappend = s_cnt[0];
-  const int ncand = nappend > MFX_S_CAP ? MFX_S_CAP : nappend;
+  const int ncand = nappend > a.scap ? a.scap : nappend;
   const double thr_fin = __longlong_as_double((long long)s_thr[0]);
   const double lost = __longlong_as_double((long long)s_thr[1]);
   __syncthreads();   // everyone has read the counters / is done with the B buffers
-  if (nappend > MFX_S_CAP && lost >= thr_fin) {
+  if (nappend > a.scap && lost >= thr_fin) {
     // an entry that could still matter was overwritten: hand the voxel to the FP64 kernel
     if (tid == 0) {
       const int slot = atomicAdd(a.fb_count, 1);
@@ -652,7 +653,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     int dbg_eval = 0;
 #endif
     // compact list of the ring entries that reach the final threshold
-    int* s_evl = (int*)((char*)smem + 2048);                       // [MFX_S_CAP], inside the idle hi image (behind s_win / s_yrec)
+    // [MFX_S_CAP] compaction list: inside the idle hi image (behind s_win / s_yrec) when that is large enough
+    int* s_evl = (KS >= 8) ? (int*)((char*)smem + 2048) : s_evl4;
     double* s_stage = (double*)sBl + (size_t)wave * 2 * MP;       // [2][MP] per wave, inside the idle lo image
     if (tid == 0) s_cnt[2] = 0;
     __syncthreads();

@@ -343,6 +343,12 @@ extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long 
 static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
 static int g_k2_maxc = MFX_MAXC;
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { g_k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
+static int g_k2s_cap = 0;   // 0: MFX_S_CAP
+extern "C" void mfx_debug_set_k2s_cap(int cap) {
+  int c = 4;
+  while (2 * c <= cap) c *= 2;   // a power of two
+  g_k2s_cap = (cap <= 0 || c >= MFX_S_CAP) ? 0 : c;
+}
 
 template <int KSTEPS, bool BRACKET, bool PIPE = true, int NW = 8, int TILES = 2, int NBUF = 2>
 static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
@@ -384,7 +390,7 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 static size_t k2s_lds_bytes(int KS, int N, bool bracket = true) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
   return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (3 * NP) + 4 * MP + 4 * 8 * 64 +
-         (bracket ? 48 * MP : 0);
+         (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
 static thread_local int g_last_fallback = 0;
@@ -413,6 +419,7 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
   aa.stamps = g_stamps;
   aa.fb_count = fb;
   aa.fb_list = fb + 1;
+  aa.scap = g_k2s_cap ? g_k2s_cap : MFX_S_CAP;
   hipLaunchKernelGGL(kern, dim3(nvox), dim3(512), lds, st, aa);
   HIPCHK(hipGetLastError());
   if (g_profiling) HIPCHK(hipEventRecord(g_ev1, st));

@@ -214,21 +214,27 @@ def test_k2_screening_kernel_equals_fp64_kernel_c2():
     d_Y += torch.from_numpy(noise).to(dev)
     lib = L.lib()
     res = []
+    nfb = []
     try:
-        for screen in (1, 0):
+        # screening kernel | FP64 kernel | screening kernel with a 32-entry short list (forces hand-backs to the FP64 kernel)
+        for screen, cap in ((1, 0), (0, 0), (1, 32)):
             lib.mfx_debug_set_k2_screen(screen)
+            lib.mfx_debug_set_k2s_cap(cap)
             out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
             L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_pk.data_ptr(), 2, 0, 0, None, None, 0, V,
                                           out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
             torch.cuda.synchronize(dev)
-            if screen:
-                nfb = lib.mfx_debug_last_fallback_count()
+            nfb.append(lib.mfx_debug_last_fallback_count() if screen else 0)
             res.append(out.cpu().numpy())
     finally:
         lib.mfx_debug_set_k2_screen(1)
+        lib.mfx_debug_set_k2s_cap(0)
     bad = np.where(np.any(res[0] != res[1], axis=1))[0]
     assert bad.size == 0, "screening kernel differs from the FP64 kernel in voxels %s" % bad[:10]
-    assert 0 <= nfb < 0.02 * V, nfb        # hand-backs to the FP64 kernel stay rare (and are bit-identical anyway)
+    assert 0 <= nfb[0] < 0.02 * V, nfb     # hand-backs to the FP64 kernel stay rare (and are bit-identical anyway)
+    bad = np.where(np.any(res[2] != res[1], axis=1))[0]
+    assert bad.size == 0, "hand-back path differs from the FP64 kernel in voxels %s" % bad[:10]
+    assert nfb[2] > 100, nfb               # the small short list did overflow: the hand-back path was exercised
     # noise-free two-fascicle voxels: the generating pair is recovered (or an exactly equivalent fit)
     assert np.max(res[0][1200:1300, 5]) < 1e-12 * 500 ** 2
 
