@@ -662,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (s_cand[cix].score >= thr_fin) s_evl[atomicAdd(&s_cnt[2], 1)] = cix;
     __syncthreads();
     const int neval = s_cnt[2];
+    MFX_STAMP(9);
     if (neval <= 24) {
       // few candidates (the usual case): one WAVE per candidate.  A thread-per-candidate loop is bound by the
       // latency of its 2 x 200 dependent-address table loads (51 k cycles whatever the count); here the 64 lanes
@@ -679,13 +680,23 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (e == 0) MFX_STAMP(15);
         // lane 0: a11 = sum d1*d1, 1: a22 = sum d2*d2, 2: a12 = sum d1*d2, 3: y1 = sum y*d1, 4: y2 = sum y*d2
         const double* pa = (lane == 1) ? s_stage + MP : (lane >= 3 ? s_y : s_stage);
         const double* pb = (lane == 0 || lane == 3) ? s_stage : s_stage + MP;
         double acc = 0.0;
         if (lane < 5) {
-#pragma unroll 16
-          for (int m = 0; m < M; ++m) acc += pa[m] * pb[m];
+          // blocks of 8 rows: sixteen 16-byte LDS reads in flight, then the 8 dependent multiply-adds in row order
+          // (a read per term leaves its ~100-cycle round trip exposed 200 times: 21 k cycles per candidate)
+          int m = 0;
+          for (; m + 8 <= M; m += 8) {
+            double2 va[4], vb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { va[q] = *(const double2*)(pa + m + 2 * q); vb[q] = *(const double2*)(pb + m + 2 * q); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc += va[q].x * vb[q].x; acc += va[q].y * vb[q].y; }
+          }
+          for (; m < M; ++m) acc += pa[m] * pb[m];
         }
         const double a11 = mfx_readlane_f64(acc, 0), a22 = mfx_readlane_f64(acc, 1), a12 = mfx_readlane_f64(acc, 2),
                      y1 = mfx_readlane_f64(acc, 3), y2 = mfx_readlane_f64(acc, 4);

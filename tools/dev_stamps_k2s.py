@@ -43,6 +43,7 @@ for nm, a_, b_ in [("phase0 y+descriptors", 0, 1), ("phase1 column stats", 1, 2)
                    ("round0: chunk loop", 4, 5), ("all rounds (2->6)", 2, 6), ("exact stage", 6, 7), ("outputs", 7, 8)]:
     print("  %-28s %10.0f cycles  %5.1f %%" % (nm, d(a_, b_), 100 * d(a_, b_) / tot))
 print("exact stage split: candidates %d | argmin %d | family passes %d" % (d(6, 13), d(13, 14), d(14, 7)))
+print("candidates split: list compaction %d | first candidate's table rows staged %d | sums + rest %d" % (d(6, 9), d(9, 15), d(15, 13)))
 fam = (s[:, 7] - s[:, 14])
 print("family passes: p10 %d p50 %d p90 %d p99 %d" % tuple(np.percentile(fam, [10, 50, 90, 99])))
 can = (s[:, 13] - s[:, 6])
