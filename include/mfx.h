@@ -142,6 +142,9 @@ void mfx_debug_set_k2_maxc(int maxc);
 /* Diagnostic: number of short-list ring entries the screening kernel uses (rounded down to a power of two;
  * default and maximum 2048, <= 0 restores the default) -- the tests lower it to force hand-backs to the FP64 kernel. */
 void mfx_debug_set_k2s_cap(int cap);
+/* Diagnostic: 2 forces the screening kernel's two-image schedule (a workgroup barrier per half-step) that otherwise
+ * serves only the shapes whose LDS footprint leaves no room for a third chunk image; any other value: automatic. */
+void mfx_debug_set_k2s_images(int nb);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,8 @@ __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo)
 }
 
 // BR: the protocol has G-bracketed rows (screening through the plan's virtual shells, exact stage as mfx_eval_br)
-template <int KS, bool BR = false>
+// NB: LDS images of D2 chunks: 3 (one workgroup barrier per chunk) where they fit beside the rest, else 2 (two barriers)
+template <int KS, bool BR = false, int NB = 3>
 __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   constexpr int WG = 512, NW = 8;
   constexpr int MP = KS * 16;  // padded measurement count
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
 
   // ---- LDS carve-up
-  _Float16* sBh = (_Float16*)smem;                 // [2][KS][64][8]  hi halves, fragment order
-  _Float16* sBl = sBh + 2 * KS * 512;              // [2][KS][64][8]  lo halves
-  double* s_y = (double*)(sBl + 2 * KS * 512);     // [MP]
+  _Float16* sBh = (_Float16*)smem;                 // [NB][KS][64][8]  hi halves, fragment order
+  _Float16* sBl = sBh + NB * KS * 512;             // [NB][KS][64][8]  lo halves
+  double* s_y = (double*)(sBl + NB * KS * 512);    // [MP]
   double* s_t0 = s_y + MP;                         // [2][MP]
   double* s_I1 = s_t0 + 2 * MP;                    // [NP] 1/|d1|   (0 beyond N)
   double* s_Z1 = s_I1 + NP;                        // [NP] d1.y/|d1| (-inf beyond N)
@@ -487,17 +488,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       continue;
     }
 
-    // ---- LDS sweep, ping-pong between the two wave groups (waves 0-3 | 4-7: one wave of each per SIMD).
-    // In every half-step one group runs the 3*KS MFMAs of a column chunk while the other one does VALU work
-    // (pair screen of its previous accumulator tile + its half of the generation of a coming chunk), so the
-    // matrix pipe and the vector ALUs of a SIMD are busy at the same time; a workgroup barrier ends each
-    // half-step.  Group g multiplies chunk c in half-step 2c+g and screens it in half-step 2c+g+1.
-    // Chunk c lives in LDS buffer c&1: it is read in half-steps 2c, 2c+1 and written in 2c-2 (group 1's half)
-    // and 2c-1 (group 0's half), i.e. while buffer (c-1)&1 is being read.
-    // Generation item = (pair of adjacent atoms, the 8 rows of one MFMA fragment); a group owns KS of the 2*KS
-    // fragment row blocks of a chunk, one item per thread.
-    // gen_load issues the table loads at the start of the group's MFMA half-step, gen_store converts and writes
-    // the FP16 hi/lo fragments in its next VALU half-step (the loads fly behind the MFMAs).
+    // ---- LDS sweep, ping-pong between the two wave groups (waves 0-3 | 4-7: one wave of each per SIMD): while one
+    // group runs the 3*KS MFMAs of a column chunk the other one does VALU work (pair screen of its previous
+    // accumulator tile + its half of the generation of a coming chunk), so the matrix pipe and the vector ALUs of
+    // a SIMD are busy at the same time.  Generation item = (pair of adjacent atoms, the 8 rows of one MFMA
+    // fragment); a group owns KS of the 2*KS fragment row blocks of a chunk, one item per thread: gen_load issues
+    // its table loads, gen_store converts and writes the FP16 hi/lo fragments.  The two schedules are below.
     const int grp = wave >> 2, tg = tid & 255;
     static_assert(KS <= 16, "one generation item per thread");
     f32x4 gd[8];   // item = (pair of adjacent atoms, the 8 rows of one fragment): 16-byte loads, see phase 1
@@ -509,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_rs[MP + 8 * q + e], nn);
     };
-    auto gen_store = [&](int ch) {
+    auto gen_store = [&](int ch, int buf) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
         h8 hi0, lo0, hi1, lo1;
@@ -524,64 +520,110 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         }
         // fragments of atoms c0, c0+1 are adjacent: 32 contiguous bytes per lane, conflict-free
         const int off = (gq * 32 + c0) << 3;
-        _Float16* dh = sBh + (ch & 1) * KS * 512 + off;
-        _Float16* dl = sBl + (ch & 1) * KS * 512 + off;
+        _Float16* dh = sBh + buf * KS * 512 + off;
+        _Float16* dl = sBl + buf * KS * 512 + off;
         *(h8*)dh = hi0; *(h8*)(dh + 8) = hi1;
         *(h8*)dl = lo0; *(h8*)(dl + 8) = lo1;
       }
     };
-
-    if (round == 0) MFX_STAMP(3);
-    // prologue: chunk 0 (both halves) and group 1's half of chunk 1
-    gen_load(0);
-    gen_store(0);
-    if (grp == 1 && ntiles > 1) { gen_load(1); gen_store(1); }
-    __syncthreads();
-    if (round == 0) MFX_STAMP(4);
-    thr = __longlong_as_double((long long)s_thr[0]);
-
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-    for (int hs = 0; hs <= 2 * ntiles; ++hs) {
-#ifdef MFX_STAMPS_HS   // diagnostic builds: start of half-steps 20..35 of round 1 as seen by wave 0 (tools/dev_stamps_hs.py)
-      if (a.stamps && round == 1 && hs >= 20 && hs < 36 && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + hs - 20] = __builtin_amdgcn_s_memtime();
-#endif
-      if ((hs & 1) == grp) {
-        // ---- MFMA half-step: chunk c = (hs - grp) / 2
-        const int c = (hs - grp) >> 1;
-        if (c < ntiles) {
-          if (c + 1 + grp < ntiles) gen_load(c + 1 + grp);   // consumed in this group's next half-step
-          if (rt_valid) {
+    // the 3*KS MFMAs of this wave's row tile against the chunk image in buffer buf
+    auto mfma_chunk = [&](int buf) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-            const _Float16* bhp = sBh + (c & 1) * KS * 512 + lane * 8;
-            const _Float16* blp = sBl + (c & 1) * KS * 512 + lane * 8;
-            h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
-            mfx_static_for<0, KS>([&](auto kc) {
-              constexpr int ks = decltype(kc)::value;
-              h8 bhn = bh, bln = bl;
-              if constexpr (ks + 1 < KS) {   // fragments of the next k-step while this one multiplies
-                bhn = *(const h8*)(bhp + (ks + 1) * 512);
-                bln = *(const h8*)(blp + (ks + 1) * 512);
-              }
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc, 0, 0, 0);
-              bh = bhn; bl = bln;
-              __builtin_amdgcn_sched_barrier(0);
-            });
-          }
+      for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+      const _Float16* bhp = sBh + buf * KS * 512 + lane * 8;
+      const _Float16* blp = sBl + buf * KS * 512 + lane * 8;
+      h8 bh = *(const h8*)bhp, bl = *(const h8*)blp;
+      mfx_static_for<0, KS>([&](auto kc) {
+        constexpr int ks = decltype(kc)::value;
+        h8 bhn = bh, bln = bl;
+        if constexpr (ks + 1 < KS) {   // fragments of the next k-step while this one multiplies
+          bhn = *(const h8*)(bhp + (ks + 1) * 512);
+          bln = *(const h8*)(blp + (ks + 1) * 512);
         }
-      } else {
-        // ---- VALU half-step: finish the generation of this group's half of chunk c + 1 + grp, screen chunk c
-        const int c = (hs - 1 - grp) >> 1;
-        if (c >= 0 && c < ntiles) {
-          if (c + 1 + grp < ntiles) gen_store(c + 1 + grp);
-          if (rt_valid) scan_tile(acc, c);
-        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afl[ks], bh, acc, 0, 0, 0);
+        bh = bhn; bl = bln;
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    if (round == 0) MFX_STAMP(3);
+    if constexpr (NB == 3) {
+      // ---- one barrier per chunk.  In period c both groups multiply chunk c - group 0 first, group 1 second - and
+      // do their VALU work in the other phase: group 0 then screens chunk c and generates its half of chunk c+2,
+      // group 1 first screens chunk c-1 and generates its half of chunk c+1.  Chunk c lives in buffer c mod 3:
+      // during period c nobody writes it, group 1 writes buffer (c+1) mod 3 (last read in period c-2) and group 0
+      // buffer (c+2) mod 3 (last read in period c-1), so the two phases of a period need no barrier between them:
+      // a wave moves on to its second phase as soon as its first is done instead of waiting for the slower group
+      // (the screening wave has nobody to cover its LDS round trips and in-order table loads: ~2 250 cycles against
+      // 1 330 for the MFMA chain when the half-steps were coupled by a barrier).
+      // Table loads of a group's next item go at the end of its VALU phase and are consumed one period later.
+      gen_load(0);
+      gen_store(0, 0);
+      if (grp == 0) {
+        if (ntiles > 1) { gen_load(1); gen_store(1, 1); }
+        if (ntiles > 2) gen_load(2);
+      } else if (ntiles > 1) {
+        gen_load(1);
       }
       __syncthreads();
+      if (round == 0) MFX_STAMP(4);
+      thr = __longlong_as_double((long long)s_thr[0]);
+      int b0 = 0;   // buffer of chunk c
+      for (int c = 0; c <= ntiles; ++c) {
+#ifdef MFX_STAMPS_HS   // diagnostic builds: start of periods 10..25 of round 1 as seen by wave 0 (tools/dev_stamps_hs.py)
+        if (a.stamps && round == 1 && c >= 10 && c < 26 && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + c - 10] = __builtin_amdgcn_s_memtime();
+#endif
+        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;   // buffers of chunks c+1, c+2
+        if (grp == 0) {
+          if (c < ntiles) {
+            if (rt_valid) mfma_chunk(b0);
+            if (c + 2 < ntiles) gen_store(c + 2, b2);
+            if (rt_valid) scan_tile(acc, c);
+            if (c + 3 < ntiles) gen_load(c + 3);
+          }
+        } else {
+          if (c + 1 < ntiles) gen_store(c + 1, b1);
+          if (c >= 1 && rt_valid) scan_tile(acc, c - 1);
+          if (c + 2 < ntiles) gen_load(c + 2);
+          if (c < ntiles && rt_valid) mfma_chunk(b0);
+        }
+        // LDS-only workgroup barrier: __syncthreads() would also wait for the table loads just issued (vmcnt)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        b0 = b1;
+      }
+    } else {
+      // ---- two chunk images: a barrier after every half-step.  Group g multiplies chunk c in half-step 2c+g and
+      // screens it in half-step 2c+g+1; chunk c lives in buffer c&1, read in half-steps 2c, 2c+1 and written in
+      // 2c-2 (group 1's half) and 2c-1 (group 0's half), i.e. while buffer (c-1)&1 is being read.  gen_load issues
+      // the table loads at the start of the group's MFMA half-step, gen_store converts and writes the FP16 hi/lo
+      // fragments in its next VALU half-step (the loads fly behind the MFMAs).
+      gen_load(0);
+      gen_store(0, 0);
+      if (grp == 1 && ntiles > 1) { gen_load(1); gen_store(1, 1); }
+      __syncthreads();
+      if (round == 0) MFX_STAMP(4);
+      thr = __longlong_as_double((long long)s_thr[0]);
+      for (int hs = 0; hs <= 2 * ntiles; ++hs) {
+        if ((hs & 1) == grp) {
+          const int c = (hs - grp) >> 1;
+          if (c < ntiles) {
+            if (c + 1 + grp < ntiles) gen_load(c + 1 + grp);   // consumed in this group's next half-step
+            if (rt_valid) mfma_chunk(c & 1);
+          }
+        } else {
+          const int c = (hs - 1 - grp) >> 1;
+          if (c >= 0 && c < ntiles) {
+            if (c + 1 + grp < ntiles) gen_store(c + 1 + grp, (c + 1 + grp) & 1);
+            if (rt_valid) scan_tile(acc, c);
+          }
+        }
+        __syncthreads();
+      }
     }
     if (round == 0) MFX_STAMP(5);
   }

@@ -343,6 +343,8 @@ extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long 
 static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
 static int g_k2_maxc = MFX_MAXC;
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { g_k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
+static int g_k2s_nb = 0;    // 0: as many chunk images as fit; 2: force the two-image schedule
+extern "C" void mfx_debug_set_k2s_images(int nb) { g_k2s_nb = (nb == 2) ? 2 : 0; }
 static int g_k2s_cap = 0;   // 0: MFX_S_CAP
 extern "C" void mfx_debug_set_k2s_cap(int cap) {
   int c = 4;
@@ -387,9 +389,9 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 }
 
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
-static size_t k2s_lds_bytes(int KS, int N, bool bracket = true) {
+static size_t k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)4 * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (3 * NP) + 4 * MP + 4 * 8 * 64 +
+  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (3 * NP) + 4 * MP + 4 * 8 * 64 +
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
@@ -397,10 +399,10 @@ static thread_local int g_last_fallback = 0;
 extern "C" int mfx_debug_last_fallback_count(void) { return g_last_fallback; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { g_k2_screen = enabled ? 1 : 0; }
 
-template <int KS, bool BR>
+template <int KS, bool BR, int NB>
 static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
-  const size_t lds = k2s_lds_bytes(KS, a.T.N, BR);
-  auto kern = mfx_fit_k2s_kernel<KS, BR>;
+  const size_t lds = k2s_lds_bytes(KS, a.T.N, BR, NB);
+  auto kern = mfx_fit_k2s_kernel<KS, BR, NB>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   struct StreamMem {   // stream-ordered allocation released on every exit path
     void* p = nullptr;
@@ -444,17 +446,20 @@ static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
   const int M = a.P.M;
   const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
-  if (g_k2_screen && M <= 256 && k2s_lds_bytes(KSm, a.T.N, a.P.any_bracket != 0) <= 160 * 1024) {
-    if (a.P.any_bracket) {
-      if (KSm == 4) return launch_k2s_t<4, true>(a, nvox, st);
-      if (KSm == 8) return launch_k2s_t<8, true>(a, nvox, st);
-      if (KSm == 13) return launch_k2s_t<13, true>(a, nvox, st);
-      return launch_k2s_t<16, true>(a, nvox, st);
-    }
-    if (KSm == 4) return launch_k2s_t<4, false>(a, nvox, st);
-    if (KSm == 8) return launch_k2s_t<8, false>(a, nvox, st);
-    if (KSm == 13) return launch_k2s_t<13, false>(a, nvox, st);
-    return launch_k2s_t<16, false>(a, nvox, st);
+  if (g_k2_screen && M <= 256) {
+    const bool br = a.P.any_bracket != 0;
+    // three chunk images (one barrier per chunk) where they fit into the 160 KB of LDS, else two
+    const int NB = (g_k2s_nb != 2 && k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);
+#define MFX_K2S_CASE(KS_, BR_, NB_) if (KSm == KS_ && br == BR_ && NB == NB_) return launch_k2s_t<KS_, BR_, NB_>(a, nvox, st)
+    MFX_K2S_CASE(4, false, 3);  MFX_K2S_CASE(4, true, 3);
+    MFX_K2S_CASE(8, false, 3);  MFX_K2S_CASE(8, true, 3);
+    MFX_K2S_CASE(13, false, 3); MFX_K2S_CASE(13, true, 3);
+    MFX_K2S_CASE(4, false, 2);  MFX_K2S_CASE(4, true, 2);
+    MFX_K2S_CASE(8, false, 2);  MFX_K2S_CASE(8, true, 2);
+    MFX_K2S_CASE(13, false, 2); MFX_K2S_CASE(13, true, 2);
+    MFX_K2S_CASE(16, false, 2); MFX_K2S_CASE(16, true, 2);
+    MFX_K2S_CASE(16, false, 3); MFX_K2S_CASE(16, true, 3);
+#undef MFX_K2S_CASE
   }
   return launch_k2_f64(a, nvox, st);
 }

@@ -382,8 +382,11 @@ def test_k2_screening_kernel_shapes(N, dirs):
     lib = L.lib()
     res = []
     try:
-        for screen in (1, 0):
+        # screening kernel (as many chunk images as fit: the one-barrier-per-chunk schedule) | FP64 kernel |
+        # screening kernel forced to its two-image schedule
+        for screen, images in ((1, 0), (0, 0), (1, 2)):
             lib.mfx_debug_set_k2_screen(screen)
+            lib.mfx_debug_set_k2s_images(images)
             out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
             L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_pk.data_ptr(), 2, 0, 0, None, None, 0, V,
                                           out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
@@ -391,8 +394,10 @@ def test_k2_screening_kernel_shapes(N, dirs):
             res.append(out.cpu().numpy())
     finally:
         lib.mfx_debug_set_k2_screen(1)
-    bad = np.where(np.any(res[0] != res[1], axis=1))[0]
-    assert bad.size == 0, "screening kernel differs from the FP64 kernel in voxels %s" % bad[:10]
+        lib.mfx_debug_set_k2s_images(0)
+    for r, what in ((res[0], "screening kernel"), (res[2], "screening kernel (two chunk images)")):
+        bad = np.where(np.any(r != res[1], axis=1))[0]
+        assert bad.size == 0, "%s differs from the FP64 kernel in voxels %s" % (what, bad[:10])
     ns = 4
     T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
     z = np.zeros(ns, bool)
