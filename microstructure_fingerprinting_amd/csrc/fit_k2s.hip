@@ -375,10 +375,20 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
       Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
     };
-    auto scan_tile = [&](const f32x16& acc, int ct) {
+    // scan_pre only ISSUES the LDS reads of a tile's column (threshold, column statistics): a screening wave has
+    // no partner to cover an LDS round trip, so they fly behind the generation work; scan_main does the rest
+    unsigned long long sc_thr = 0ull;
+    float sc_z2 = 0.0f, sc_s = 0.0f;
+    auto scan_pre = [&](int ct) {
+      const int j = ct * 32 + lr;
+      sc_thr = s_thr[0];
+      sc_z2 = s_Zf[NP + j];
+      sc_s = s_cs[j];
+    };
+    auto scan_main = [&](const f32x16& acc, int ct) {
       const int j = ct * 32 + lr;
       // row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ct*32 + lr
-      thr = fmax(thr, __longlong_as_double((long long)s_thr[0]));
+      thr = fmax(thr, __longlong_as_double((long long)sc_thr));
       // 1/sqrt(T), T = thr rounded down, the reciprocal root rounded up (v_rsq_f32: 1 ulp)
       const float rth = __builtin_amdgcn_rsqf(fmaxf((float)thr * (1.0f - 2e-7f), 1e-30f)) * (1.0f + 4e-7f);
       float* pqw = s_pq + wave * 64;
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           pqw[32 + lane] = ok ? Q : 1e18f;
         }
       }
-      const float z2f = s_Zf[NP + j], sj = s_cs[j];
+      const float z2f = sc_z2, sj = sc_s;
       float P2, Q2;
       pq_of(z2f, rth, P2, Q2);
       const bool colok = sj > 0.0f;
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         }
       }
     };
+    auto scan_tile = [&](const f32x16& acc, int ct) { scan_pre(ct); scan_main(acc, ct); };
 
     if (tail) {
       thr = __longlong_as_double((long long)s_thr[0]);
@@ -505,13 +516,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_rs[MP + 8 * q + e], nn);
     };
+    // the item's interpolation offsets are the same for every chunk of the round: registers, not LDS
+    float g_t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g_t[e] = s_t0f[MP + 8 * (gact ? gq : KS * grp) + e];
     auto gen_store = [&](int ch, int buf) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
         h8 hi0, lo0, hi1, lo1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float t = s_t0f[MP + 8 * gq + e];
+          const float t = g_t[e];
           _Float16 x, y;
           mfx_split16(fmaf(gd[e][1], t, gd[e][0]), x, y);
           hi0[e] = x; lo0[e] = y;
@@ -581,14 +596,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;   // buffers of chunks c+1, c+2
         if (grp == 0) {
           if (c < ntiles) {
-            if (rt_valid) mfma_chunk(b0);
+            if (rt_valid) { mfma_chunk(b0); scan_pre(c); }
             if (c + 2 < ntiles) gen_store(c + 2, b2);
-            if (rt_valid) scan_tile(acc, c);
+            if (rt_valid) scan_main(acc, c);
             if (c + 3 < ntiles) gen_load(c + 3);
           }
         } else {
+          if (c >= 1 && rt_valid) scan_pre(c - 1);
           if (c + 1 < ntiles) gen_store(c + 1, b1);
-          if (c >= 1 && rt_valid) scan_tile(acc, c - 1);
+          if (c >= 1 && rt_valid) scan_main(acc, c - 1);
           if (c + 2 < ntiles) gen_load(c + 2);
           if (c < ntiles && rt_valid) mfma_chunk(b0);
         }
