@@ -101,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
   float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
-  float* s_cs = s_Zf + 2 * NP;                     // [NP] 2^8 |d2|: cosine -> accumulator factor of a D2 column (0: no such atom)
-  float* s_yf = s_cs + NP;                         // [MP] FP32 copy of y (ranking statistics)
+  float* s_cs = s_Zf + 2 * NP;                     // [2][NP] |d1| | |d2| (FP32, table units; 0: no such atom): accumulator = cosine |d1| |d2|
+  float* s_yf = s_cs + 2 * NP;                     // [MP] FP32 copy of y (ranking statistics)
   float* s_pq = s_yf + MP;                         // [NW][2][32] pair-screen constants of each wave's 32 rows
   // bracketed protocols: exact-stage descriptors of the upper shell, and separate screening row offsets
   double* s_t1 = (double*)(s_pq + NW * 64);        // [2][MP]
@@ -181,13 +181,14 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   {
     // The vector-memory pipe of a CU retires roughly one wave load per 20 cycles whatever its width (<= 16 B per
     // lane), and this kernel issues ~1e4 of them per voxel: table entries are therefore fetched two atoms at a
-    // time (16 B: {ylo, slope} of atoms n, n+1).  Column pairs are laid out as v in [0, VH): atoms 2v, 2v+1 of D1,
-    // v in [VH, 2 VH): of D2, VH a multiple of 64 so that the direction is wave-uniform; a thread accumulates its
-    // pairs v = tid + 512 p, all passes at once: independent loads in flight, and the per-row constants (knot
-    // row, offset, y) come from LDS as one 16-byte broadcast read per four rows.
+    // time (16 B: {ylo, slope} of atoms n, n+1).  A thread accumulates the column pairs v = tid + 512 p (atoms 2v,
+    // 2v+1), all passes at once: independent loads in flight, and the per-row constants (knot row, offset, y)
+    // come from LDS as one 16-byte broadcast read per four rows.
     // Ranking statistics only (FP32 table, fused ops): the exact stage re-sums in reference order.
+    // Only D2 here: the statistics of D1 fall out of the A-operand generation of each round (the table is then
+    // read once for both purposes: the L2 -> L1 fill rate, ~32 B/clk, is what bounds these passes).
     const int VH = ((N + 1) / 2 + 63) & ~63;
-    const int npass = (2 * VH + WG - 1) / WG;
+    const int npass = (VH + WG - 1) / WG;
     for (int p0 = 0; p0 < npass; p0 += 2) {
       int kq[2], nq[2];
       bool wact[2];
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int v = tid + WG * (p0 + q);
-        kq[q] = v >= VH;
-        nq[q] = 2 * (v - kq[q] * VH);
+        kq[q] = 1;
+        nq[q] = 2 * v;
         wact[q] = __any((p0 + q < npass) && (nq[q] < N));
         a2[q][0] = a2[q][1] = ay[q][0] = ay[q][1] = 0.0;
       }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             (k ? s_I2 : s_I1)[n] = inv;
             (k ? s_Z2 : s_Z1)[n] = act ? z : -INFINITY;
             s_Zf[k * NP + n] = act ? (float)z : -1e30f;
-            if (k) s_cs[n] = (act && inv > 0.0) ? (float)(sqrt(a2[q][u]) * (double)MFX_S_SCALE) : 0.0f;
+            s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
             const double s = z > 0.0 ? z * z : 0.0;
             if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
           }
@@ -266,12 +267,13 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
   }
   // best single atom of each dictionary (first index on ties): they stand for every pair whose optimum
-  // has one active atom (mf_utils.py:357-379); the exact stage expands the winner's family
+  // has one active atom (mf_utils.py:357-379); the exact stage expands the winner's family.  D2's here, D1's
+  // after the rounds (its statistics come with the A operands); the threshold starts from what is known.
   {
     double* s_bs = s_red;            // [2][8]
     int* s_bn = (int*)(s_red + 16);  // [2][8]
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 1; k < 2; ++k) {
       double s = my_s[k];
       int n = my_n[k];
 #pragma unroll
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     __syncthreads();
     if (tid == 0) {
       double best1 = 0.0;
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 1; k < 2; ++k) {   // D1's best single atom is known after the last round (see there)
         double s = s_bs[k * 8];
         int n = s_bn[k * 8];
         for (int w = 1; w < 8; ++w) {
@@ -323,6 +325,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   };
 
   MFX_STAMP(2);
+  double bs1 = 0.0;   // best single atom of D1 among the row tiles this wave has generated
+  int bn1 = 0;
   const int nrounds = (ntiles + NW - 1) / NW;
   for (int round = 0; round < nrounds; ++round) {
     // A last round with ONE row tile left (N = 782: 25 = 3*8 + 1) is shared by all waves: each keeps the same
@@ -332,12 +336,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     const int rt = tail ? round * NW : round * NW + wave;
     const bool rt_valid = rt < ntiles;  // wave-uniform
     const int rtc = rt_valid ? rt : 0;
-    // A operand: this wave's 32 atoms of D1 (normalised, split), all KS k-steps, in registers
+    // A operand: this wave's 32 atoms of D1, all KS k-steps, split in registers - UN-normalised like D2 (the table
+    // is pre-scaled to values <= 128), so that the column statistics I1 = 1/|d1|, Z1 = d1.y/|d1| fall out of the
+    // same read of the table (ranking only, as in phase 1; a lane sums its half of the rows, the halves meet
+    // through one cross-lane exchange): the L2 -> L1 fill rate bounds these passes, not the arithmetic.
     h8 afh[KS], afl[KS];
     {
       const int n = rtc * 32 + lr;
-      const float asc = rt_valid ? (float)s_I1[n] * MFX_S_SCALE : 0.0f;
       const int nn = min(n, ldn - 1);
+      double a2 = 0.0, ay = 0.0;
       mfx_static_for<0, KS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
         float2 d[8];
@@ -346,14 +353,45 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         h8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+          float fv = fmaf(d[j].y, s_t0f[16 * ks + 8 * lh + j], d[j].x);
+          fv = rt_valid ? fv : 0.0f;
+          const double fd = (double)fv;
+          a2 = fma(fd, fd, a2);
+          ay = fma((double)s_yf[16 * ks + 8 * lh + j], fd, ay);
           _Float16 x, y;
-          mfx_split16(fmaf(d[j].y, s_t0f[16 * ks + 8 * lh + j], d[j].x) * asc, x, y);
+          mfx_split16(fv, x, y);
           vh[j] = x; vl[j] = y;
         }
         asm volatile("" : "+v"(vh), "+v"(vl));   // materialise here: the conversions must not sink below all loads
         afh[ks] = vh; afl[ks] = vl;
         __builtin_amdgcn_sched_barrier(0);
       });
+      a2 += __shfl_xor(a2, 32);
+      ay += __shfl_xor(ay, 32);
+      const bool act = rt_valid && n < N;
+      const double nrm = sqrt(a2);
+      const double inv = (act && a2 > 0.0) ? 1.0 / nrm : 0.0;
+      const double z = ay * inv;
+      if (rt_valid && lh == 0) {
+        s_I1[n] = inv;
+        s_Z1[n] = act ? z : -INFINITY;
+        s_Zf[n] = act ? (float)z : -1e30f;
+        s_cs[n] = (act && a2 > 0.0) ? (float)nrm : 0.0f;
+      }
+      // best single atom of D1 so far (first index on ties: rounds and lanes go in increasing n)
+      double sb = (act && z > 0.0) ? z * z : 0.0;
+      int nb = n;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const double s2 = __shfl_xor(sb, o);
+        const int n2 = __shfl_xor(nb, o);
+        const bool take = (s2 > sb) || (s2 == sb && n2 < nb);
+        sb = take ? s2 : sb;
+        nb = take ? n2 : nb;
+      }
+      if (sb > bs1) { bs1 = sb; bn1 = nb; }
+      // a pair matters only if it beats every single atom
+      if (lane == 0 && sb - mrg > 0.0) atomicMax(&s_thr[0], mfx_nonneg_bits(sb - mrg));
     }
 
     // pair screen of one 32x32 accumulator tile against column tile ct (used by the LDS sweep and by the tail round)
@@ -366,9 +404,14 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // P_i = cos theta_i, Q_i = sin theta_i (the other branch of S(c) >= T, c >= cos(theta1 - theta2), has a
     // non-positive weight).  The test is therefore  c~ - DC <= P1 P2 - Q1 Q2  with T = the running threshold;
     // a STALE (lower) threshold, P rounded up and Q rounded down only let more pairs through.  In accumulator
-    // units (c = acc / s_cs[j]):  t = P1 (P2 s) - Q1 (Q2 s) - acc,  pass when  max t + DCF s >= 0.  Rows and
-    // columns beyond N get constants that never pass.  Only a register group with a passing pair runs the FP64
-    // criteria below (one out-of-line copy).
+    // units (acc = c |d1| |d2|, neither operand is normalised) the margin is folded into the constants,
+    //     (P1 + D)(P2 + D) - (1 - D)^2 Q1 Q2  >=  P1 P2 - Q1 Q2 + D      for all P, Q = sqrt(1 - P^2) in [0, 1]
+    // (the difference is D (P1 + P2 + (2 - D) Q1 Q2 - 1) + D^2 and P1 + P2 + 1.99 Q1 Q2 >= 1 on the unit square),
+    // at the price of a margin up to ~3 D instead of D:
+    //     t = ((P1 + D) n1)((P2 + D) n2) - ((1 - D) Q1 n1)((1 - D) Q2 n2) - acc,      pass when max t >= 0:
+    // two FMAs and a max per pair, from two constants per row and two per column.  Rows and columns beyond N get
+    // constants that do not pass (but for the corner cases noted below).  Only a register group with a passing
+    // pair runs the FP64 criteria below (one out-of-line copy).
     double thr = 0.0, thr_rows = -1.0;
     constexpr float DCF = (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       const int j = ct * 32 + lr;
       sc_thr = s_thr[0];
       sc_z2 = s_Zf[NP + j];
-      sc_s = s_cs[j];
+      sc_s = s_cs[NP + j];
     };
     auto scan_main = [&](const f32x16& acc, int ct) {
       const int j = ct * 32 + lr;
@@ -395,19 +438,21 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (thr > thr_rows) {   // wave-uniform: the threshold rose since this wave's row constants were made
         thr_rows = thr;
         if (lane < 32) {
-          const float z1 = s_Zf[rtc * 32 + lane];
+          const float z1 = s_Zf[rtc * 32 + lane], n1 = s_cs[rtc * 32 + lane];
           float P, Q;
           pq_of(z1, rth, P, Q);
-          const bool ok = z1 > -1e29f;
-          pqw[lane] = ok ? P : -1e18f;
-          pqw[32 + lane] = ok ? Q : 1e18f;
+          // beyond N: (0, 1e18) for rows, (-1e18, 1e18) for columns: t < 0 but for a padded row against a column
+          // with Q2 = 0 (its atom alone reaches the threshold), which the FP64 criteria reject
+          const bool ok = n1 > 0.0f;
+          pqw[lane] = ok ? (P + DCF) * n1 : 0.0f;
+          pqw[32 + lane] = ok ? Q * ((1.0f - DCF) * n1) : 1e18f;
         }
       }
-      const float z2f = sc_z2, sj = sc_s;
+      const float z2f = sc_z2, n2 = sc_s;
       float P2, Q2;
       pq_of(z2f, rth, P2, Q2);
-      const bool colok = sj > 0.0f;
-      const float p2 = colok ? P2 * sj : 0.0f, q2 = colok ? Q2 * sj : 1e18f, dcj = colok ? DCF * sj : -1e30f;
+      const bool colok = n2 > 0.0f;
+      const float p2 = colok ? (P2 + DCF) * n2 : -1e18f, q2 = colok ? Q2 * ((1.0f - DCF) * n2) : 1e18f;
       float mm[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -417,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         float t[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) t[u] = fmaf(-q1q[u], q2, fmaf(p1q[u], p2, -acc[4 * q + u]));
-        mm[q] = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + dcj;
+        mm[q] = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
       }
       if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
         // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
@@ -429,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * q + gg;
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            const double c = (double)acc[g] * (s_I2[j] * (1.0 / MFX_S_SCALE));
+            const double c = (double)acc[g] * (s_I1[i] * s_I2[j]);
             const double z1 = s_Z1[i];
             const double e1 = fma(-c, z2, z1);
             const double e2 = fma(-c, z1, z2);
@@ -643,6 +688,25 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
     if (round == 0) MFX_STAMP(5);
   }
+  // D1's best single atom (first index on ties) joins the candidates, like D2's after phase 1
+  {
+    double* s_bs = s_red;            // [8]
+    int* s_bn = (int*)(s_red + 16);  // [8]
+    if (lane == 0) { s_bs[wave] = bs1; s_bn[wave] = bn1; }
+    __syncthreads();
+    if (tid == 0) {
+      double sb = s_bs[0];
+      int nb = s_bn[0];
+      for (int w = 1; w < NW; ++w) {
+        const double s2 = s_bs[w];
+        const int n2 = s_bn[w];
+        if (s2 > sb || (s2 == sb && n2 < nb)) { sb = s2; nb = n2; }
+      }
+      s_cnt[3] = -1;
+      if (sb > 0.0) { s_cnt[3] = s_cnt[0] & (a.scap - 1); push(sb + mrg, nb, 0); }   // [3]: its slot (diagnostics)
+    }
+    __syncthreads();
+  }
 
   MFX_STAMP(6);
   // ---- exact stage (same as fit_k2.hip phase 3): reference arithmetic and order on the short list
@@ -765,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #ifdef MFX_STAMPS
         if (lane == 0) {
           ++dbg_eval;
-          if (cix >= 2 && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+          if (cix >= 1 && cix != s_cnt[3] && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
         }
 #endif
         __builtin_amdgcn_wave_barrier();
@@ -780,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
 #ifdef MFX_STAMPS
         ++dbg_eval;
-        if (cix >= 2 && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+        if (cix >= 1 && cix != s_cnt[3] && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
 #endif
       }
     }

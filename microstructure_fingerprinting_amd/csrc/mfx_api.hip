@@ -391,7 +391,7 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
 static size_t k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (3 * NP) + 4 * MP + 4 * 8 * 64 +
+  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP + 4 * 8 * 64 +
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
