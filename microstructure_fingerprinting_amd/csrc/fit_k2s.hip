@@ -53,14 +53,12 @@ __device__ __forceinline__ double mfx_readlane_f64(double v, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// The A operand (D1 tile) is normalised and scaled by 2^8 (one per-atom factor); the B operand (D2) is NOT normalised --
-// the FP32 screening table is pre-scaled on the host so that its values are <= 128, and the column's 1/|d2| is folded
-// into the factor that turns an accumulator entry into the cosine (one multiply per pair either way).  Both are split
-// WITHOUT rescaling the low half:  f = hi + lo + r,  hi = f with its mantissa truncated to 10 bits (exact in FP16),
-// lo = fp16(f - hi),  |r| <= 2^-21 |f|.  With |f| <= 256 the low halves sit around 256 * 2^-10 * |a|: normal FP16
-// numbers for all but negligible entries (an FP16 subnormal still resolves 6e-8, i.e. 2e-10 of a column norm),
-// so hi.hi, hi.lo and lo.hi can share ONE FP32 accumulator and c~ = acc * (1/|d2|) * 2^-8.
-#define MFX_S_SCALE 256.0f
+// Neither operand is normalised: the FP32 screening table is pre-scaled on the host so that its values are <= 128,
+// the accumulator holds cosine * |d1| * |d2| and the norms sit in the per-atom constants of the pair screen.  Both
+// operands are split WITHOUT rescaling the low half:  f = hi + lo + r,  hi = f with its mantissa truncated to 10 bits
+// (exact in FP16),  lo = fp16(f - hi),  |r| <= 2^-21 |f|.  With |f| <= 128 the low halves sit around 2^-10 |f|:
+// normal FP16 numbers for all but negligible entries (an FP16 subnormal still resolves 6e-8, i.e. ~1e-10 of a column
+// norm), so hi.hi, hi.lo and lo.hi can share ONE FP32 accumulator.
 __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo) {
   // f must be ONE rounded FP32 value for both uses below (the compiler may otherwise fold the producing multiply
   // into a mixed-precision FMA for one use and not for the other: the halves then miss f by an FP16 ulp)
@@ -77,7 +75,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   constexpr int WG = 512, NW = 8;
   constexpr int MP = KS * 16;  // padded measurement count
   extern __shared__ double smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int M = a.P.M, N = a.T.N, ldn = a.T.ldn;
   const int NP = (N + 31) & ~31;  // atoms padded to a multiple of 32
@@ -172,10 +171,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 
   MFX_STAMP(1);
   // ---- phase 1: column statistics; y_sq sequential as mf_utils.py:307-325
-  double y_sq = 0.0;
-  for (int m = 0; m < M; ++m) y_sq += s_y[m] * s_y[m];
-  const double mrg = MFX_S_DC * y_sq;        // |S(c~) - S(c)| <= mrg
-  const double etol = MFX_S_DC * sqrt(y_sq); // |e(c~) - e(c)| <= etol
+  double y_sq_v = 0.0;
+  for (int m = 0; m < M; ++m) y_sq_v += s_y[m] * s_y[m];
+  // wave-uniform values that live through the whole kernel go to scalar registers (the vector file is full)
+  const double y_sq = mfx_readlane_f64(y_sq_v, 0);
+  const double mrg = mfx_readlane_f64(MFX_S_DC * y_sq, 0);        // |S(c~) - S(c)| <= mrg
+  const double etol = mfx_readlane_f64(MFX_S_DC * sqrt(y_sq), 0); // |e(c~) - e(c)| <= etol
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
   {
@@ -389,6 +390,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         sb = take ? s2 : sb;
         nb = take ? n2 : nb;
       }
+      sb = mfx_readlane_f64(sb, 0);
+      nb = __builtin_amdgcn_readfirstlane(nb);
       if (sb > bs1) { bs1 = sb; bn1 = nb; }
       // a pair matters only if it beats every single atom
       if (lane == 0 && sb - mrg > 0.0) atomicMax(&s_thr[0], mfx_nonneg_bits(sb - mrg));
@@ -688,10 +691,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
     if (round == 0) MFX_STAMP(5);
   }
+  // (the thread index is re-derived here instead of being kept - spilled, 4 KB of scratch per voxel - across the sweep)
+  tid = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   // D1's best single atom (first index on ties) joins the candidates, like D2's after phase 1
   {
-    double* s_bs = s_red;            // [8]
-    int* s_bn = (int*)(s_red + 16);  // [8]
+    double* s_bs = (double*)smem + 64;            // [8]  inside the chunk images, idle from here on (a constant
+    int* s_bn = (int*)((double*)smem + 80);       // [8]  address: nothing to keep in a register across the sweep)
     if (lane == 0) { s_bs[wave] = bs1; s_bn[wave] = bn1; }
     __syncthreads();
     if (tid == 0) {

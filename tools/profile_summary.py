@@ -7,8 +7,12 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kern = sys.argv[1] if len(sys.argv) > 1 else "mfx_fit_k2s_kernel"
 tag = sys.argv[2] if len(sys.argv) > 2 else "k2s"
 res = collections.defaultdict(float)
-for f in glob.glob(R + '/gpurun_out/prof_pmc_*/runc/*_counter_collection.csv'):
-    for r in csv.DictReader(open(f)):
+# gpurun merges new outputs into gpurun_out/ without removing older ones: take the newest run of every counter group
+for d in glob.glob(R + '/gpurun_out/prof_pmc_*/runc'):
+    fs = sorted(glob.glob(d + '/*_counter_collection.csv'), key=os.path.getmtime)
+    if not fs:
+        continue
+    for r in csv.DictReader(open(fs[-1])):
         if kern in r['Kernel_Name']:
             res[r['Counter_Name']] += float(r['Counter_Value'])
 V = 100000
@@ -31,9 +35,9 @@ out = {"round": 1,
        "mfma_pipe_utilisation": res['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc_xcd,
        "valu_insts_per_mfma": res['SQ_INSTS_VALU'] / max(res['SQ_INSTS_MFMA'], 1)}
 json.dump(out, open(R + '/profiles/r01_pmc_traffic_%s.json' % tag, 'w'), indent=1)
-ks = glob.glob(R + '/gpurun_out/prof_stats/runc/*_kernel_stats.csv')
+ks = sorted(glob.glob(R + '/gpurun_out/prof_stats/runc/*_kernel_stats.csv'), key=os.path.getmtime)
 if ks:
-    rows = list(csv.reader(open(ks[0])))
+    rows = list(csv.reader(open(ks[-1])))
     with open(R + '/profiles/r01_kernel_stats_%s.csv' % tag, 'w') as f:
         w = csv.writer(f)
         for r in rows[:6]:
