@@ -89,17 +89,13 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   _Float16* sBl = sBh + NB * KS * 512;             // [NB][KS][64][8]  lo halves
   double* s_y = (double*)(sBl + NB * KS * 512);    // [MP]
   double* s_t0 = s_y + MP;                         // [2][MP]
-  double* s_I1 = s_t0 + 2 * MP;                    // [NP] 1/|d1|   (0 beyond N)
-  double* s_Z1 = s_I1 + NP;                        // [NP] d1.y/|d1| (-inf beyond N)
-  double* s_I2 = s_Z1 + NP;
-  double* s_Z2 = s_I2 + NP;
-  double* s_red = s_Z2 + NP;                       // [32] scratch
+  double* s_red = s_t0 + 2 * MP;                   // [32] scratch
   Cand* s_cand = (Cand*)(s_red + 32);              // [MFX_S_CAP]
   unsigned long long* s_thr = (unsigned long long*)(s_cand + MFX_S_CAP);  // [0] threshold bits, [1] lost-entry max bits
   int* s_r0 = (int*)(s_thr + 2);                   // [2][MP] knot row * ldn (element offset of the row in the table)
   int* s_cnt = s_r0 + 2 * MP;                      // [4]
   float* s_t0f = (float*)(s_cnt + 4);              // [2][MP] FP32 copy of s_t0 for the screening passes
-  float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] FP32 copies of Z1 | Z2 (-1e30 beyond N)
+  float* s_Zf = s_t0f + 2 * MP;                    // [2][NP] Z1 | Z2 = d.y/|d| of the rotated atoms (-1e30 beyond N)
   float* s_cs = s_Zf + 2 * NP;                     // [2][NP] |d1| | |d2| (FP32, table units; 0: no such atom): accumulator = cosine |d1| |d2|
   float* s_yf = s_cs + 2 * NP;                     // [MP] FP32 copy of y (ranking statistics)
   float* s_pq = s_yf + MP;                         // [NW][2][32] pair-screen constants of each wave's 32 rows
@@ -256,8 +252,6 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             const bool act = n < N;
             const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
             const double z = ay[q][u] * inv;
-            (k ? s_I2 : s_I1)[n] = inv;
-            (k ? s_Z2 : s_Z1)[n] = act ? z : -INFINITY;
             s_Zf[k * NP + n] = act ? (float)z : -1e30f;
             s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
             const double s = z > 0.0 ? z * z : 0.0;
@@ -374,8 +368,6 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       const double inv = (act && a2 > 0.0) ? 1.0 / nrm : 0.0;
       const double z = ay * inv;
       if (rt_valid && lh == 0) {
-        s_I1[n] = inv;
-        s_Z1[n] = act ? z : -INFINITY;
         s_Zf[n] = act ? (float)z : -1e30f;
         s_cs[n] = (act && a2 > 0.0) ? (float)nrm : 0.0f;
       }
@@ -469,7 +461,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       }
       if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
         // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
-        const double z2 = s_Z2[j];
+        // the column statistics are ranking-grade anyway (FP32 table): their FP32 copies serve here too
+        // (6e-8 relative: ~4e-7 |y|^2 in a score, against the margin of 1e-5 |y|^2)
+        const double z2 = (double)s_Zf[NP + j], n2d = (double)s_cs[NP + j];
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
           if (!__any(mm[q] >= 0.0f)) continue;
@@ -477,8 +471,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * q + gg;
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-            const double c = (double)acc[g] * (s_I1[i] * s_I2[j]);
-            const double z1 = s_Z1[i];
+            const double n12 = (double)s_cs[i] * n2d;
+            const double c = n12 > 0.0 ? (double)acc[g] / n12 : 0.0;
+            const double z1 = (double)s_Zf[i];
             const double e1 = fma(-c, z2, z1);
             const double e2 = fma(-c, z1, z2);
             const double den = fma(-c, c, 1.0);

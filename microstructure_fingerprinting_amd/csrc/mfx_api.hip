@@ -381,7 +381,11 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
   const int M = a.P.M;
   const bool br = a.P.any_bracket != 0;
   if (M <= 64) return br ? launch_k2_t<16, true>(a, nvox, st) : launch_k2_t<16, false>(a, nvox, st);
-  if (M <= 200) return br ? launch_k2_t<50, true>(a, nvox, st) : launch_k2_t<50, false>(a, nvox, st);
+  if (M <= 200) {
+    if (k2_lds_bytes(50, br, a.T.ldn, 2, 2) <= 160 * 1024) return br ? launch_k2_t<50, true>(a, nvox, st) : launch_k2_t<50, false>(a, nvox, st);
+    // large dictionaries (N > 960): the single-tile single-buffer form, one wave per SIMD
+    return br ? launch_k2_t<50, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<50, false, false, 4, 1, 1>(a, nvox, st);
+  }
   // long protocols: one wave per SIMD (512 registers hold the A operand), single-tile single-buffer chunks
   if (M <= 400) return br ? launch_k2_t<100, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<100, false, false, 4, 1, 1>(a, nvox, st);
   if (M <= 560) return br ? launch_k2_t<140, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<140, false, false, 4, 1, 1>(a, nvox, st);
@@ -391,7 +395,7 @@ static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
 // ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
 static size_t k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
-  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 4 * NP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP + 4 * 8 * 64 +
+  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP + 4 * 8 * 64 +
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
@@ -442,11 +446,21 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
   return rc;
 }
 
+// whether launch_k2_f64 can serve this plan: the screening kernel hands voxels back to it, so it runs only then
+static bool k2_f64_fits(const FitK2Args& a) {
+  const int M = a.P.M;
+  const bool br = a.P.any_bracket != 0;
+  if (M > 560) return false;
+  const size_t lds = M <= 64 ? k2_lds_bytes(16, br, a.T.ldn, 2, 2) : M <= 200 ? k2_lds_bytes(50, br, a.T.ldn, 1, 1)
+                   : M <= 400 ? k2_lds_bytes(100, br, a.T.ldn, 1, 1) : k2_lds_bytes(140, br, a.T.ldn, 1, 1);
+  return lds <= 160 * 1024;
+}
+
 static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
   const int M = a.P.M;
   const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
-  if (g_k2_screen && M <= 256) {
+  if (g_k2_screen && M <= 256 && k2_f64_fits(a)) {
     const bool br = a.P.any_bracket != 0;
     // three chunk images (one barrier per chunk) where they fit into the 160 KB of LDS, else two
     const int NB = (g_k2s_nb != 2 && k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);

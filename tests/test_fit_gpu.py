@@ -352,7 +352,7 @@ def test_k2_dictionary_units(unit):
 
 @pytest.mark.parametrize("N,dirs", [(31, [20, 20, 20]), (32, [9, 9, 9]), (33, [40, 41, 42]), (64, [60, 60, 60]), (255, [20, 21, 20]),
                                     (257, [66, 66, 66]), (288, [30, 30, 30]), (289, [12, 12, 12]), (513, [40, 40, 40]),
-                                    (545, [66, 67, 66]), (800, [33, 33, 33]), (100, [84, 84, 84])])
+                                    (545, [66, 67, 66]), (800, [33, 33, 33]), (100, [84, 84, 84]), (1100, [33, 33, 33])])
 def test_k2_screening_kernel_shapes(N, dirs):
     """Tile/round/tail logic of the screening kernel across dictionary sizes (1 round, full rounds, a single leftover
     row tile shared by all waves: 9, 17 and 25 tiles) and protocol lengths (the KS = 4, 8, 13, 16 instantiations):
