@@ -560,16 +560,20 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       for (int e = 0; e < 8; ++e) gd[e] = tab32x2_at(s_rs[MP + 8 * q + e], nn);
     };
     // the item's interpolation offsets are the same for every chunk of the round: registers, not LDS
-    float g_t[8];
+    // (not for KS = 16: its A tile takes 128 registers and every further one spills)
+    constexpr bool GT = KS <= 13;
+    float g_t[GT ? 8 : 1];
+    if constexpr (GT) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g_t[e] = s_t0f[MP + 8 * (gact ? gq : KS * grp) + e];
+      for (int e = 0; e < 8; ++e) g_t[e] = s_t0f[MP + 8 * (gact ? gq : KS * grp) + e];
+    }
     auto gen_store = [&](int ch, int buf) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
         h8 hi0, lo0, hi1, lo1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float t = g_t[e];
+          const float t = GT ? g_t[GT ? e : 0] : s_t0f[MP + 8 * gq + e];
           _Float16 x, y;
           mfx_split16(fmaf(gd[e][1], t, gd[e][0]), x, y);
           hi0[e] = x; lo0[e] = y;
