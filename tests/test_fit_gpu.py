@@ -239,6 +239,62 @@ def test_k2_screening_kernel_equals_fp64_kernel_c2():
     assert np.max(res[0][1200:1300, 5]) < 1e-12 * 500 ** 2
 
 
+def test_k2_full_size_bench_workload_screening_equals_fp64_kernel():
+    """BASELINE config 2 at its full size, the very voxels bench.py times (1e5 voxels, 782 atoms x 200 measurements,
+    seeds as in bench.py): every output of the screening kernel bit-identical to the FP64 kernel's; properties that
+    do not depend on the size: fractions in [0, 1] summing to 1, atom ids inside the dictionary, MSE close to the
+    noise variance, and a sample equal to the CPU oracle."""
+    import torch
+    import bench
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from oracle import oracle as orc
+    V = 100000
+    sch, dic, ms = bench.build_model(782)
+    dev = torch.device("cuda", 0)
+    ms.device = 0
+    plan = engine.Plan(ms.device_tables(), scheme=sch)
+    M, N = sch.shape[0], ms.num_subs
+    rng = np.random.default_rng(1000)
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    atoms = rng.integers(0, N, (V, 2)).astype(np.int32)
+    nu = rng.dirichlet(np.ones(2), V)
+    d_pk = torch.from_numpy(peaks).to(dev)
+    d_Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
+    for k in range(2):
+        col = engine.rotate_columns_dev(plan, d_pk[:, 3 * k:3 * k + 3].contiguous(), torch.from_numpy(atoms[:, k].copy()).to(dev))
+        d_Y += 500.0 * torch.from_numpy(nu[:, k:k + 1].copy()).to(dev) * col
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    d_Y += torch.randn((V, M), dtype=torch.float64, device=dev, generator=gen) * (500.0 / 30.0)
+    lib = L.lib()
+    res = []
+    try:
+        for screen in (1, 0):
+            lib.mfx_debug_set_k2_screen(screen)
+            out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
+            L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_pk.data_ptr(), 2, 0, 0, None, None, 0, V,
+                                          out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            torch.cuda.synchronize(dev)
+            res.append(out.cpu().numpy())
+    finally:
+        lib.mfx_debug_set_k2_screen(1)
+    a, b = res
+    bad = np.where(np.any(a != b, axis=1))[0]
+    assert bad.size == 0, "screening kernel differs from the FP64 kernel in voxels %s" % bad[:10]
+    # layout [M0, nu1, nu2, id1, id2, MSE, R2] (mf.py:375-450)
+    assert np.all(a[:, 0] > 0) and np.all((a[:, 1:3] >= 0) & (a[:, 1:3] <= 1))
+    np.testing.assert_allclose(a[:, 1] + a[:, 2], 1.0, rtol=0, atol=1e-12)
+    assert np.all((a[:, 3:5] >= 0) & (a[:, 3:5] < N)) and np.all(a[:, 3:5] == np.round(a[:, 3:5]))
+    assert abs(a[:, 5].mean() / (500.0 / 30.0) ** 2 - 1.0) < 0.05
+    sel = np.arange(0, V, V // 6)[:6]
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    z = np.zeros(sel.size, bool)
+    ref = orc.fit_batch(T, sch, d_Y[torch.from_numpy(sel).to(dev)].cpu().numpy(), np.full(sel.size, 2), z, z,
+                        np.ascontiguousarray(peaks[sel]), 2, False, False, None, None, 0, nthreads=8)
+    _check(a[sel], ref, 2)
+
+
 def test_k2_screening_kernel_bracketed_protocol():
     """Protocol whose gradient strengths fall BETWEEN the dictionary's shells (UKBB-like: a handful of distinct G values,
     mf_utils.py:1827-1839): the screening kernel ranks through the plan's virtual shells (blend of the two bracketing
