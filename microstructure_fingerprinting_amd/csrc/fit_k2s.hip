@@ -853,13 +853,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       }
     }
 #ifdef MFX_STAMPS
+    MFX_STAMP(13);   // before the diagnostics below: 512 global atomics would count as exact-stage time
     if (a.stamps) {
-      atomicMax(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)__double_as_longlong(dbg_err));
-      atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)dbg_eval);
+      if (dbg_err > 0.0) atomicMax(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)__double_as_longlong(dbg_err));
+      if (dbg_eval > 0) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], (unsigned long long)dbg_eval);
       if (tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)nappend;
     }
-#endif
+#else
     MFX_STAMP(13);
+#endif
     block_argmin(res, idx, w0, w1);
     MFX_STAMP(14);
   }
