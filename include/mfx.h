@@ -16,8 +16,15 @@
  *     device and never keeps a host pointer after return.  Opaque handles (mfx_tables,
  *     mfx_plan) are library-owned and freed by their *_destroy function.
  *   - "_dev" variants take DEVICE pointers (HBM-resident inputs/outputs, e.g. torch
- *     tensors' data_ptr) and a hipStream_t passed as void*; they enqueue work and do
- *     not synchronise.
+ *     tensors' data_ptr) and a hipStream_t passed as void*; they only enqueue work on that
+ *     stream (kernels, stream-ordered allocations) and never wait for the device.  What the
+ *     reference would raise from inside its voxel loop (a fascicle direction that is not a
+ *     unit vector, mf_utils.py:1798-1802) cannot be returned by an asynchronous call: the
+ *     kernels flag it in the plan's status word, mfx_plan_status() reports it.  Exception:
+ *     mfx_monte_carlo_average_dev returns its (small) result in a host array and therefore
+ *     waits for its own work.
+ *   - all library state that is not owned by a handle (last error, timing events, diagnostic
+ *     switches, hand-back counters) is per host thread: one host thread drives one GPU.
  *   - there is no CPU fallback: every compute entry point fails with MFX_ERR_NO_DEVICE
  *     when no gfx950 device is usable.
  */
@@ -66,6 +73,10 @@ int mfx_plan_create_multishell(const mfx_tables* t, const double* scheme, int M,
 int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs, const int32_t* shell_of_row, int M,
                              mfx_plan** out);
 void mfx_plan_destroy(mfx_plan* p);
+/* Deferred error channel of the asynchronous entry points: waits for `stream`, reports and clears what the fit
+ * kernels launched with this plan have flagged since the last call: MFX_ERR_DIR_NORM if a voxel's fascicle
+ * direction failed the reference's unit-norm check (mf_utils.py:1798-1802, raised there per voxel), else MFX_OK. */
+int mfx_plan_status(const mfx_plan* p, void* stream);
 
 /* ---- batched rotation: B directions -> out [B x M x N].
  * Replaces interp_PGSE_from_multishell(sch_mat, newdir, msinterp=...) (mf_utils.py:1693-1956)
@@ -93,6 +104,12 @@ int mfx_rotate_cols_dev(const mfx_plan* p, const double* d_dirs, const int32_t* 
 int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf, const uint8_t* ear,
                   const double* peaks, int maxfasc, int csf_on, int ear_on, const double* sig_csf,
                   const double* sig_ear, int E, int64_t V, double* params_out);
+/* Same, with the reference's ROI gather `data[mask > 0]` (mf.py:644, 1020-1022) fused into the upload: voxel v's
+ * signal is the M doubles at Y + rows[v] * M (rows == NULL: rows[v] = v).  Y is read chunk by chunk through pinned
+ * staging buffers while the kernels of the previous chunks run (copy and compute streams).                    */
+int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K, const uint8_t* csf,
+                       const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
+                       const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out);
 /* Device-resident variant: all pointers are device pointers.  Only the homogeneous class
  * "every voxel has K == maxfasc, csf == csf_on, ear == ear_on" is accepted (that is what a
  * benchmark or a pre-binned caller has); mixed batches go through mfx_fit_batch.        */
@@ -131,14 +148,20 @@ void mfx_set_profiling(int enabled);
 /* Diagnostic builds only (-DMFX_STAMPS): device buffer [grid x 16] of s_memtime stamps written by the
  * K=2 kernel at its phase boundaries; a no-op in the shipped build.                                */
 void mfx_debug_set_stamps(void* dev_ptr);
-/* Diagnostic: number of two-fascicle voxels of the last mfx_fit_batch*_ class launch on this thread that the
- * split-FP16 screening kernel handed back to the FP64 kernel (short-list overflow); 0 in the normal case. */
+/* Diagnostic: number of voxels of the last mfx_fit_batch* call on this thread that a fused kernel could not decide
+ * from its short list and redid exactly: two-fascicle voxels the split-FP16 screening kernel handed back to the FP64
+ * kernel (ring overflow or screening-error guard), and two-fascicle + CSF/EAR voxels that took the exhaustive exact
+ * pass; 0 in the normal case.  The counters are summed on the device and copied behind the kernels: this call waits
+ * for that copy (the fit calls themselves never do).  ..._guard_count: how many of them the screening-error guard sent. */
 int mfx_debug_last_fallback_count(void);
+int mfx_debug_last_guard_count(void);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs
  * (default and maximum 256; 0 forces that pass for every voxel -- used by the tests to cover it). */
 void mfx_debug_set_k2_maxc(int maxc);
+/* Diagnostic: the same for the two-fascicle + CSF/EAR kernel (default and maximum 256; 0 forces its exhaustive pass). */
+void mfx_debug_set_k2x_maxc(int maxc);
 /* Diagnostic: number of short-list ring entries the screening kernel uses (rounded down to a power of two;
  * default and maximum 2048, <= 0 restores the default) -- the tests lower it to force hand-backs to the FP64 kernel. */
 void mfx_debug_set_k2s_cap(int cap);

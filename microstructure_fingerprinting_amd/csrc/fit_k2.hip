@@ -39,6 +39,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MFX_WG 512
 #define MFX_MAXC 256
+#define MFX_S_CAP 2048      // screening kernel (fit_k2s.hip): ring entries (power of two): two full single-atom families (2 x 782) fit
 #define MFX_DET_REL 1e-8   // pairs with 1 - cos^2 below this are ranked as single atoms
 #define MFX_A12_REL 4e-14  // bound on the relative rounding difference of an MFMA-summed Gram entry
 
@@ -49,6 +50,7 @@ struct FitK2Args {
   const double* peaks;  // [V x peaks_ld]
   int peaks_ld;
   const int* vox_list;  // [nvox] or null (identity)
+  const int* list_count;  // null, or device word holding the number of valid vox_list entries (blocks beyond it exit)
   double* params;       // [V x num_params]
   int num_params;
   int maxfasc;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
   const int NP = ldn;  // atoms padded to a multiple of 16
   const int ntiles = NP >> 4;
   const double2* __restrict__ tab = a.T.tab;
+  if (a.list_count && (int)blockIdx.x >= *a.list_count) return;   // device-side hand-back list (fit_k2s.hip): workgroup-uniform
   const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
 
   // ---- LDS carve-up
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     }
   }
   if (tid == 0) s_cnt[0] = 0;
+  if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
 
   auto elem = [&](int k, int m, int n) -> double {

@@ -36,7 +36,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#define MFX_S_CAP 2048      // ring entries (power of two): two full single-atom families (2 x 782) fit
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
 
@@ -141,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
   }
   if (tid == 0) { s_cnt[0] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
 
   // table entry (row offset ro, atom n) through a 32-bit element offset: SGPR base + VGPR offset addressing

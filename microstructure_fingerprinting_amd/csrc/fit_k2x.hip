@@ -8,6 +8,20 @@
 // HBM scratch slab and staged through LDS.  Short-listed tuples are re-evaluated with the reference's
 // exact arithmetic (Cramer + explicit residual for _3; Gram-based active-set optimum + explicit residual
 // for _4up, whose reference is the third-party scipy.optimize.nnls).  VALU-bound (the epilogue dominates).
+//
+// What is ranked where (no candidate is ever dropped silently):
+//   * the pair scan ranks, per (i1,i2), only the supports that contain BOTH fascicle atoms ({1,2}, {1,2,f}, {1,2,x_t},
+//     {1,2,f,x_t}); one best per (lane,row) slot goes to the short list, and a slot whose runner-up is also within
+//     rounding distance of the optimum sends its whole slot row to the exact stage;
+//   * supports with ONE fascicle atom are scored per atom (U_k[n][t], from the per-atom inner products), those with none
+//     per extra tuple (Q[t]): when such a support is within rounding distance of the optimum, EVERY tuple sharing its
+//     active atoms ties (a voxel fitted by one fascicle + CSF, a pure CSF voxel ...), so the exact stage evaluates the
+//     whole family in the reference's arithmetic and scan order - as the reference's strict-'<' first hit demands -
+//     instead of letting the ties flood the short list (one entry per slot and round: that list used to overflow and
+//     drop entries silently);
+//   * every short-listed pair is evaluated exactly for ALL its extra tuples t (they tie when the extra column is inactive);
+//   * a short list that still overflows triggers the exhaustive exact pass over all N*N*ntup tuples (slow, exact by
+//     construction, counted in the launch's overflow counter).
 #pragma once
 #include "fit_small.hip"  // ExtrasDev, mfx_np_sumsq
 #include "mfx_device.h"
@@ -31,6 +45,14 @@ struct FitK2XArgs {
   double* ws;  // [gridDim.x][2][NP][MFX_XS] scratch: atom . extra-column inner products
   int num_params, maxfasc, csf_on, ear_on;
   int vox_base;  // first voxel (or first vox_list entry) of this launch
+  int maxc;      // short-list size beyond which the exhaustive exact pass runs (MFX_XMAXC; tests lower it)
+  int* ovf_count;  // [0] voxels that took the exhaustive pass (null: not counted)
+};
+
+#define MFX_XFAM 64   // family items (see below) per voxel before the exhaustive pass takes over
+struct FamX {
+  int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (all i, all j, t)   4: (i, j = lc mod 16, all t)
+  int a, t;
 };
 
 struct CandX {
@@ -70,13 +92,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double* s_Yx = s_a2x + 2 * 16 * MFX_XS;         // [XS]
   double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
   double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
-  // feasible-support tables (strides NX+1: entry NX = the support with the fixed CSF column only)
-  const int TS = NX + 1;
-  double* s_Qx = s_red + 32;                      // [XS]            supports without a fascicle atom
-  double* s_R1 = s_Qx + MFX_XS;                   // [NW][16][TS]    supports {d1_i} + extras
-  double* s_R2 = s_R1 + NW * 16 * TS;             // [2][16][TS]     supports {d2_j} + extras
-  CandX* s_cand = (CandX*)(s_R2 + 2 * 16 * TS);   // [XMAXC]
-  int* s_r0 = (int*)(s_cand + MFX_XMAXC);         // [2][MP]
+  double* s_Qx = s_red + 32;                      // [XS]            best support made of extra columns only, per extra tuple
+  CandX* s_cand = (CandX*)(s_Qx + MFX_XS);        // [XMAXC]
+  FamX* s_fam = (FamX*)(s_cand + MFX_XMAXC);      // [XFAM]
+  int* s_r0 = (int*)(s_fam + MFX_XFAM);           // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;
   int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);
 
@@ -101,7 +120,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     const int p = q / MFX_XS, r = q - p * MFX_XS;
     s_Gxx[q] = (p < NX && r < NX) ? a.X.Gxx[p * NX + r] : 0.0;
   }
-  if (tid == 0) s_cnt[0] = 0;
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+  if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
   if (tid < MFX_XS) {
     double s = 0.0;
@@ -119,6 +139,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     if (HASF) q = fmax(q, fmax(pos1(s_Gxx[0], s_Yx[0]), pos2(s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], s_Yx[0], s_Yx[cx])));
     s_Qx[tid] = q;
   }
+  const double eps_abs_of = 1e-9;
 
   auto elem = [&](int k, int m, int n) -> double {
     if (BRACKET) {
@@ -131,9 +152,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     }
   };
 
+  __syncthreads();   // s_Qx
+  // best score over the supports {atom} + subset of {fixed, x_t}: every support with exactly ONE fascicle atom
+  auto atom_best = [&](double a11, double y1, const double* ax /* atom . extras */, int t) -> double {
+    const int cx = x0 + t;
+    double r = fmax(pos1(a11, y1), pos2(a11, ax[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[cx]));
+    if (HASF) r = fmax(r, fmax(pos2(a11, ax[0], s_Gxx[0], y1, s_Yx[0]),
+                                pos3(a11, ax[0], ax[cx], s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[0], s_Yx[cx])));
+    return r;
+  };
   // ---- phase 1: column statistics + inner products with the extra columns (sequential over rows)
   double y_sq_seq = 0.0;
   for (int m = 0; m < M; ++m) y_sq_seq += s_y[m] * s_y[m];
+  double umax = 0.0;
   for (int col = tid; col < 2 * NP; col += WG) {
     const int k = col >= NP, n = col - k * NP;
     double a2 = 0.0, ay = 0.0, ax[MFX_XS];
@@ -151,40 +182,38 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     }
     (k ? s_A22 : s_A11)[n] = a2;
     (k ? s_Y2 : s_Y1)[n] = ay;
+    double* axp = wsA + ((size_t)k * NP + n) * MFX_XS;
 #pragma unroll
-    for (int e = 0; e < MFX_XS; ++e) wsA[((size_t)k * NP + n) * MFX_XS + e] = ax[e];
+    for (int e = 0; e < MFX_XS; ++e) axp[e] = ax[e];
+    // (scored from the slab, not from ax[]: a dynamically indexed register array would live in scratch)
+    if (n < N)
+      for (int t = 0; t < ntup; ++t) umax = fmax(umax, atom_best(a2, ay, axp, t));
   }
+  for (int t = 0; t < ntup; ++t) umax = fmax(umax, s_Qx[t]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) umax = fmax(umax, __shfl_xor(umax, o));
+  if (lane == 0) s_red[wave] = umax;
   __syncthreads();
   const double y_sq = (Kp == 4) ? s_red[16] : y_sq_seq;
+  // running best score (same value in every thread): starts from the supports with fewer than two fascicle atoms
+  double gmax_run = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) gmax_run = fmax(gmax_run, s_red[w]);
+  __syncthreads();   // s_red is reused by the rounds
 
-  // best support {atom} + subset of {fixed, x_t} with a non-negative solution, t = TS-1: {atom, fixed} only
-  auto atom_supports = [&](double a11, double y1, const double* ax /* atom . extras, stride 1 */, int t) -> double {
-    if (t == NX) return HASF ? pos2(a11, ax[0], s_Gxx[0], y1, s_Yx[0]) : 0.0;
-    if (t >= ntup) return 0.0;
-    const int cx = x0 + t;
-    double r = pos2(a11, ax[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[cx]);
-    if (HASF) r = fmax(r, pos3(a11, ax[0], ax[cx], s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[0], s_Yx[cx]));
-    return r;
-  };
   auto gen_chunk = [&](int ch, int buf) {
     const int c = tid & 15, m0 = tid >> 4;  // WG/16 row groups
     const int n = ch * 16 + c;
     double* dst = sB + (size_t)buf * (MP * 16) + c;
     for (int m = m0; m < MP; m += WG / 16) dst[m * 16] = elem(1, m, n);
-    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms and their one-atom supports
+    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms
       const int cc = tid / MFX_XS, e = tid - cc * MFX_XS;
-      const double* ax = wsA + ((size_t)NP + ch * 16 + cc) * MFX_XS;
-      s_a2x[(buf * 16 + cc) * MFX_XS + e] = ax[e];
-      if (e < TS) {
-        const int n = ch * 16 + cc;
-        s_R2[(buf * 16 + cc) * TS + e] = (n < N) ? atom_supports(s_A22[n], s_Y2[n], ax, e) : 0.0;
-      }
+      s_a2x[(buf * 16 + cc) * MFX_XS + e] = wsA[((size_t)NP + ch * 16 + cc) * MFX_XS + e];
     }
   };
 
   const int nrounds = (ntiles + NW - 1) / NW;
-  const double eps_abs = 1e-9 * y_sq;
-  double gmax_run = 0.0;
+  const double eps_abs = eps_abs_of * y_sq;
 
   for (int round = 0; round < nrounds; ++round) {
     const int rt = round * NW + wave;
@@ -195,15 +224,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     // stage this wave's A1x rows
     if (rt_valid) {
       for (int q = lane; q < 16 * MFX_XS; q += 64) s_a1x[wave * 16 * MFX_XS + q] = wsA[((size_t)rt * 16) * MFX_XS + q];
-      for (int q = lane; q < 16 * TS; q += 64) {
-        const int il = q / TS, t = q - il * TS, i = rt * 16 + il;
-        s_R1[(wave * 16 + il) * TS + t] = (i < N) ? atom_supports(s_A11[i], s_Y1[i], wsA + (size_t)i * MFX_XS, t) : 0.0;
-      }
     }
-    double bs[4];
-    int bj[4], be[4];
+    double bs[4], bs2[4];   // best and runner-up score of the (lane,row) slot
+    int bj[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bj[r] = -1; be[r] = 0; }
+    for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bs2[r] = 0.0; bj[r] = -1; }
 
     gen_chunk(0, 0);
     __syncthreads();
@@ -222,14 +247,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bp[kk * 64], acc, 0, 0, 0);
         const int j = ch * 16 + lc;
         if (j < N) {
-          // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports
-          // whose unconstrained solution is non-negative.  Supports without both fascicle atoms come from
-          // the tables; per pair the {1,2}(+fixed) block is eliminated once (LDL^T), per extra column only
-          // the last row is added -> ~30 VALU per tuple instead of a full 3x3/4x4 solve with fallbacks.
+          // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports whose
+          // unconstrained solution is non-negative.  Only the supports with BOTH fascicle atoms are ranked here (the
+          // others come from the per-atom scores, see the top of the file); per pair the {1,2}(+fixed) block is
+          // eliminated once (LDL^T), per extra column only the last row is added.
           const double a22 = s_A22[j], y2 = s_Y2[j];
-          const double s2 = pos1(a22, y2);
           const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
-          const double* R2 = s_R2 + (buf * 16 + lc) * TS;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int il = lg + 4 * r;
@@ -237,7 +260,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
             if (i < N) {
               const double a11 = s_A11[i], y1 = s_Y1[i], a12 = acc[r];
               const double* a1x = s_a1x + (wave * 16 + il) * MFX_XS;
-              const double* R1 = s_R1 + (wave * 16 + il) * TS;
               // LDL^T of the {1,2} block
               const double ip1 = mfx_rcp(a11);
               const double l21 = a12 * ip1;
@@ -248,9 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
               const double v1 = y1 * ip1, v2 = u2 * ip2;
               const double S2u = fma(u2, v2, y1 * v1);
               const double w1p = fma(-l21, v2, v1);
-              // best support inside {1,2}: both atoms, or the better single atom
-              double base = fmax((y1 > 0.0) ? y1 * v1 : 0.0, s2);
-              base = (ok2 && w1p >= 0.0 && v2 >= 0.0) ? fmax(base, S2u) : base;
+              double s = (ok2 && w1p >= 0.0 && v2 >= 0.0) ? S2u : 0.0;   // {1,2}
               // fixed (CSF) column: extend the elimination by one row
               double l31 = 0.0, b23 = 0.0, l32 = 0.0, ip3 = 0.0, u3 = 0.0, v3 = 0.0, S3u = 0.0;
               bool ok3 = false;
@@ -267,13 +287,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                 S3u = fma(u3, v3, S2u);
                 const double w2f = fma(-l32, v3, v2);
                 const double w1f = fma(-l31, v3, fma(-l21, w2f, v1));
-                base = fmax(base, fmax(R1[NX], R2[NX]));                  // {1,f}, {2,f}
-                base = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(base, S3u) : base;  // {1,2,f}
+                s = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(s, S3u) : s;  // {1,2,f}
               }
               for (int t = 0; t < ntup; ++t) {
                 const int cx = x0 + t;
                 const double a1e = a1x[cx], a2e = a2x[cx], aee = s_Gxx[cx * MFX_XS + cx], ye = s_Yx[cx];
-                double s = fmax(base, fmax(s_Qx[t], fmax(R1[t], R2[t])));
                 // support {1,2,x}: last row of the LDL^T on top of the {1,2} block
                 const double m1 = a1e * ip1;
                 const double t2 = fma(-m1, a12, a2e);
@@ -300,8 +318,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                   const double w1 = fma(-m1, w4, fma(-l31, w3, fma(-l21, w2, v1)));
                   s = (ok4 && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0 && w4 >= 0.0) ? fmax(s, fma(u4, w4, S3u)) : s;
                 }
-                if (s > bs[r]) { bs[r] = s; bj[r] = j; be[r] = t; }
               }
+              // slot update: columns come in increasing j, strict '>' keeps the first of equal scores
+              const bool better = s > bs[r];
+              bs2[r] = better ? bs[r] : fmax(bs2[r], s);
+              bj[r] = better ? j : bj[r];
+              bs[r] = better ? s : bs[r];
             }
           }
         }
@@ -328,29 +350,54 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
           s_cand[slot].score = bs[r];
           s_cand[slot].i = rt * 16 + lg + 4 * r;
           s_cand[slot].j = bj[r];
-          s_cand[slot].e = be[r];
+          s_cand[slot].e = 0;
+        }
+        if (bs2[r] >= thr) {   // the slot's runner-up could be the reference's pick too: its whole slot row goes exact
+          const int f = atomicAdd(&s_cnt[1], 1);
+          if (f < MFX_XFAM) { s_fam[f].type = 4; s_fam[f].a = rt * 16 + lg + 4 * r; s_fam[f].t = lc; }
         }
       }
     }
     __syncthreads();
   }
 
-  // ---- exact re-evaluation of the short list
-  int ncand = s_cnt[0];
-  ncand = ncand > MFX_XMAXC ? MFX_XMAXC : ncand;
+  // ---- one-atom and no-atom supports within rounding distance of the optimum -> family items
   const double thr_final = gmax_run - eps_abs;
+  for (int col = tid; col < 2 * NP; col += WG) {
+    const int k = col >= NP, n = col - k * NP;
+    if (n < N) {
+      const double a2 = (k ? s_A22 : s_A11)[n], ay = (k ? s_Y2 : s_Y1)[n];
+      const double* axp = wsA + ((size_t)k * NP + n) * MFX_XS;
+      for (int t = 0; t < ntup; ++t)
+        if (atom_best(a2, ay, axp, t) >= thr_final) {
+          const int f = atomicAdd(&s_cnt[1], 1);
+          if (f < MFX_XFAM) { s_fam[f].type = 1 + k; s_fam[f].a = n; s_fam[f].t = t; }
+        }
+    }
+  }
+  if (tid < ntup && s_Qx[tid] >= thr_final) {
+    const int f = atomicAdd(&s_cnt[1], 1);
+    if (f < MFX_XFAM) { s_fam[f].type = 3; s_fam[f].a = 0; s_fam[f].t = tid; }
+  }
   __syncthreads();
-  // scratch inside the (now idle) B buffers: 6*XMAXC + 8 + MP doubles must fit in 2*MP*16
-  static_assert(NBUF * MP * 16 >= 6 * MFX_XMAXC + 8 + MP, "B buffers too small for the exact-stage scratch");
-  double* s_rres = (double*)sB;                  // [XMAXC]
-  long* s_rkey = (long*)(s_rres + MFX_XMAXC);    // [XMAXC]
-  double* s_rw = (double*)(s_rkey + MFX_XMAXC);  // [XMAXC][4]
-  double* s_win = s_rw + 4 * MFX_XMAXC;          // res, w0..w3, key
+
+  // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
+  const int nappend = s_cnt[0], nfam_app = s_cnt[1];
+  const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
+  const bool exhaustive = nappend > a.maxc || nfam_app > MFX_XFAM;   // workgroup-uniform
+  __syncthreads();
+  // scratch inside the (now idle) B buffers
+  static_assert(NBUF * MP * 16 >= 8 * NW + 16 + MP, "B buffers too small for the exact-stage scratch");
+  double* s_rres = (double*)sB;                  // [NW]
+  long* s_rkey = (long*)(s_rres + NW);           // [NW]
+  double* s_rw = (double*)(s_rkey + NW);         // [NW][4]
+  double* s_win = s_rw + 4 * NW;                 // res, w0..w3, key
   double* s_yrec = s_win + 8;                    // [MP]
   double res = INFINITY, w[4] = {0.0, 0.0, 0.0, 0.0};
   long key = -1;
-  if (tid < ncand && s_cand[tid].score >= thr_final) {
-    const int i = s_cand[tid].i, j = s_cand[tid].j, t = s_cand[tid].e;
+  // one tuple (i, j, t) exactly: _3 = Cramer test + explicit residual (mf_utils.py:554-593), _4up = active-set optimum
+  // from a sequentially summed Gram + explicit residual (mf_utils.py:640-649); keeps the lexicographic (res, scan key) minimum
+  auto consider = [&](int i, int j, int t) {
     const int c3 = (Kp == 3) ? t : 0, c4 = 1 + t;
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0, a13 = 0.0, a23 = 0.0, a14 = 0.0, a24 = 0.0;
     for (int m = 0; m < M; ++m) {
@@ -360,6 +407,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       a13 += d1 * x3; a23 += d2 * x3;
       if (Kp == 4) { const double x4 = xx[(size_t)m * NX + c4]; a14 += d1 * x4; a24 += d2 * x4; }
     }
+    double r, u[4] = {0.0, 0.0, 0.0, 0.0};
+    long k;
     if (Kp == 3) {
       auto explicit_res = [&](const double* ww) {
         double rr = 0.0;
@@ -369,31 +418,67 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         }
         return rr;
       };
-      nnls3_cramer(y_sq, a11, a12, a13, a22, a23, s_Gxx[c3 * MFX_XS + c3], y1, y2, s_Yx[c3], explicit_res, w, res);
-      key = ((long)t * N + i) * N + j;  // scan order of _3: i3 -> i1 -> i2
+      nnls3_cramer(y_sq, a11, a12, a13, a22, a23, s_Gxx[c3 * MFX_XS + c3], y1, y2, s_Yx[c3], explicit_res, u, r);
+      k = ((long)t * N + i) * N + j;  // scan order of _3: i3 -> i1 -> i2
     } else {
       const double g[10] = {a11, a12, a13, a14, a22, a23, a24, s_Gxx[0], s_Gxx[c4], s_Gxx[c4 * MFX_XS + c4]};
       const double yy[4] = {y1, y2, s_Yx[0], s_Yx[c4]};
-      nnls_gram_subsets(4, g, yy, w);
+      nnls_gram_subsets(4, g, yy, u);
       double rr = 0.0;
       for (int m = 0; m < M; ++m) {
-        const double tt = (w[0] * elem(0, m, i) + w[1] * elem(1, m, j) + w[2] * xx[(size_t)m * NX] + w[3] * xx[(size_t)m * NX + c4] - s_y[m]);
+        const double tt = (u[0] * elem(0, m, i) + u[1] * elem(1, m, j) + u[2] * xx[(size_t)m * NX] + u[3] * xx[(size_t)m * NX + c4] - s_y[m]);
         rr += tt * tt;
       }
-      res = rr;
-      key = ((long)i * N + j) * E + t;  // itertools.product order, last index fastest
+      r = rr;
+      k = ((long)i * N + j) * E + t;  // itertools.product order, last index fastest
+    }
+    if (r < res || (r == res && k < key)) { res = r; key = k; w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = u[3]; }
+  };
+  if (exhaustive) {
+    // The short list overflowed: nothing above can be trusted.  Last resort, exact by construction: every tuple
+    // through the reference arithmetic (tens of milliseconds for this voxel).
+    if (tid == 0 && a.ovf_count) atomicAdd(a.ovf_count, 1);
+    const long nall = (long)N * N * ntup;
+    for (long q = tid; q < nall; q += WG) {
+      const int t = (int)(q % ntup);
+      const long pr = q / ntup;
+      consider((int)(pr / N), (int)(pr % N), t);
+    }
+  } else {
+    // short-listed pairs, every extra tuple (they tie when the extra column is inactive)
+    for (int q = tid; q < ncand * ntup; q += WG) {
+      const int c = q / ntup, t = q - c * ntup;
+      if (s_cand[c].score >= thr_final) consider(s_cand[c].i, s_cand[c].j, t);
+    }
+    for (int f = 0; f < nfam_app; ++f) {   // workgroup-uniform loop
+      const int type = s_fam[f].type, fa = s_fam[f].a, ft = s_fam[f].t;
+      if (type == 1) { for (int n = tid; n < N; n += WG) consider(fa, n, ft); }
+      else if (type == 2) { for (int n = tid; n < N; n += WG) consider(n, fa, ft); }
+      else if (type == 3) { for (long q = tid; q < (long)N * N; q += WG) consider((int)(q / N), (int)(q % N), ft); }
+      else {   // 4: row fa, columns ft, ft + 16, ...: the (lane,row) slot of the scan, all extra tuples
+        const int ncol = (N - ft + 15) / 16;
+        for (int q = tid; q < ncol * ntup; q += WG) consider(fa, ft + 16 * (q / ntup), q % ntup);
+      }
     }
   }
-  if (tid < MFX_XMAXC) {
-    s_rres[tid] = res;
-    s_rkey[tid] = key;
-    s_rw[4 * tid] = w[0]; s_rw[4 * tid + 1] = w[1]; s_rw[4 * tid + 2] = w[2]; s_rw[4 * tid + 3] = w[3];
+  // lexicographic (res, key) minimum over the workgroup, folded into the reference's initial state (w = 0, indices 0,
+  // min_obj = y_sq; strict '<')
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double r2 = __shfl_xor(res, o);
+    const long k2 = __shfl_xor(key, o);
+    double u[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = __shfl_xor(w[q], o);
+    const bool take = (k2 >= 0) && (key < 0 || r2 < res || (r2 == res && k2 < key));
+    if (take) { res = r2; key = k2; w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = u[3]; }
   }
+  if (lane == 0) { s_rres[wave] = res; s_rkey[wave] = key; for (int q = 0; q < 4; ++q) s_rw[4 * wave + q] = w[q]; }
   __syncthreads();
   if (tid == 0) {
     double br = y_sq, bw[4] = {0.0, 0.0, 0.0, 0.0};  // initial state of the reference: w = 0, indices 0
     long bk = -1;
-    for (int c = 0; c < ncand; ++c) {
+    for (int c = 0; c < NW; ++c) {
       const double r = s_rres[c];
       const long k = s_rkey[c];
       if (k < 0) continue;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
   for (int m = tid; m < M; m += MFX_SWG) s_y[m] = yv[m];
   if (K == 1) {
     const double* pk = a.peaks + (size_t)vox * a.peaks_ld;
+    if (tid == 0) mfx_check_dir(a.P, pk, vox);
     for (int m = tid; m < M; m += MFX_SWG) {
       const RowDesc rd = mfx_row_desc(a.T, a.P, m, pk[0], pk[1], pk[2]);
       s_r0[m] = rd.r0; s_t0[m] = rd.t0; s_r1[m] = rd.r1; s_t1[m] = rd.t1;

@@ -2,63 +2,129 @@
 // Owns device tables/plans, bins voxels by compartment class, launches the HIP kernels.
 // There is deliberately no CPU compute path in this file: without a usable gfx950 device
 // every compute entry point returns MFX_ERR_NO_DEVICE.
-#include "../../include/mfx.h"
-
-#include <hip/hip_runtime.h>
+#include "mfx_host.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
-#include "fit_k2.hip"
-#include "fit_k2s.hip"
 #include "fit_small.hip"
-#include "fit_k2x.hip"
+#include "extras.hip"
 #include "rotate.hip"
 #include "solve_generic.hip"
 #include "mc_average.hip"
 #include "mfx_device.h"
 
 // ---------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static thread_local int g_ev_launches = 0;
-static thread_local bool g_ev_valid = false;
-static bool g_profiling = false;
+// per-thread state (mfx_host.h): error string, timing events, diagnostic switches
+MfxThread& mfx_thread() {
+  static thread_local MfxThread t;
+  return t;
+}
 
-static int fail(int code, const char* fmt, ...) {
+int mfx_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  g_err = buf;
+  mfx_thread().err = buf;
   return code;
 }
-#define HIPCHK(x)                                                                              \
-  do {                                                                                         \
-    hipError_t e_ = (x);                                                                       \
-    if (e_ != hipSuccess) return fail(MFX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
-  } while (0)
+#define fail mfx_fail
 
-extern "C" const char* mfx_last_error(void) { return g_err.c_str(); }
-extern "C" int mfx_abi_version(void) { return 1; }
+int mfx_prof_begin(hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  if (!T.profiling) return MFX_OK;
+  if (!T.ev0) { HIPCHK(hipEventCreate(&T.ev0)); HIPCHK(hipEventCreate(&T.ev1)); }
+  T.ev_valid = false;
+  HIPCHK(hipEventRecord(T.ev0, st));
+  return MFX_OK;
+}
+int mfx_prof_end(hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  if (!T.profiling) return MFX_OK;
+  HIPCHK(hipEventRecord(T.ev1, st));
+  T.ev_launches = 1;
+  T.ev_valid = true;
+  return MFX_OK;
+}
+__global__ void mfx_fb_add_kernel(const int* __restrict__ cnt, int n, int* __restrict__ tot) {
+  if (threadIdx.x < n) atomicAdd(&tot[threadIdx.x], cnt[threadIdx.x]);
+}
+static int fb_setup() {
+  MfxThread& T = mfx_thread();
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (T.fb_dev && T.fb_device == dev) return MFX_OK;
+  if (T.fb_dev) { (void)hipFree(T.fb_dev); T.fb_dev = nullptr; }
+  HIPCHK(hipMalloc((void**)&T.fb_dev, 4 * sizeof(int)));
+  T.fb_device = dev;
+  if (!T.fb_host) {
+    HIPCHK(hipHostMalloc((void**)&T.fb_host, 4 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&T.fb_event, hipEventDisableTiming));
+  }
+  return MFX_OK;
+}
+int mfx_fb_begin(hipStream_t st) {
+  if (int rc = fb_setup()) return rc;
+  HIPCHK(hipMemsetAsync(mfx_thread().fb_dev, 0, 4 * sizeof(int), st));
+  return MFX_OK;
+}
+int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  if (!T.fb_dev) return MFX_OK;   // (a launcher used outside mfx_fit_batch*: nothing to report to)
+  hipLaunchKernelGGL(mfx_fb_add_kernel, dim3(1), dim3(64), 0, st, d_counters, n < 4 ? n : 4, T.fb_dev);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+int mfx_fb_end(hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  if (!T.fb_dev) return MFX_OK;
+  HIPCHK(hipMemcpyAsync(T.fb_host, T.fb_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(T.fb_event, st));
+  T.fb_pending = true;
+  return MFX_OK;
+}
+static int fb_read(int which) {
+  MfxThread& T = mfx_thread();
+  if (!T.fb_host) return 0;
+  if (T.fb_pending) { if (hipEventSynchronize(T.fb_event) != hipSuccess) return -1; T.fb_pending = false; }
+  return T.fb_host[which];
+}
+
+extern "C" const char* mfx_last_error(void) { return mfx_thread().err.c_str(); }
+extern "C" int mfx_abi_version(void) { return 2; }
 extern "C" int mfx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-extern "C" void mfx_set_profiling(int enabled) { g_profiling = enabled != 0; }
+extern "C" void mfx_set_profiling(int enabled) { mfx_thread().profiling = enabled != 0; }
 extern "C" double mfx_last_kernel_ms(void) {
-  if (!g_ev_valid || !g_ev0 || !g_ev1 || g_ev_launches == 0) return -1.0;
-  if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+  MfxThread& T = mfx_thread();
+  if (!T.ev_valid || !T.ev0 || !T.ev1 || T.ev_launches == 0) return -1.0;
+  if (hipEventSynchronize(T.ev1) != hipSuccess) return -1.0;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
-  return (double)ms / g_ev_launches;
+  if (hipEventElapsedTime(&ms, T.ev0, T.ev1) != hipSuccess) return -1.0;
+  return (double)ms / T.ev_launches;
+}
+extern "C" int mfx_debug_last_fallback_count(void) { return fb_read(0); }
+extern "C" int mfx_debug_last_guard_count(void) { return fb_read(1); }
+extern "C" void mfx_debug_set_k2_screen(int enabled) { mfx_thread().k2_screen = enabled ? 1 : 0; }
+extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (unsigned long long*)dev_ptr; }
+extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
+extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }
+extern "C" void mfx_debug_set_k2s_images(int nb) { mfx_thread().k2s_nb = (nb == 2) ? 2 : 0; }
+extern "C" void mfx_debug_set_k2s_cap(int cap) {
+  int c = 4;
+  while (2 * c <= cap) c *= 2;   // a power of two
+  mfx_thread().k2s_cap = (cap <= 0 || c >= MFX_S_CAP) ? 0 : c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -73,6 +139,9 @@ struct mfx_tables {
   void* dtab = nullptr;
   void* dtab32 = nullptr;
   void* dG = nullptr;
+  ~mfx_tables() {   // also runs when mfx_tables_create gives up half way
+    (void)hipFree(dx); (void)hipFree(doff); (void)hipFree(dtab); (void)hipFree(dtab32); (void)hipFree(dG);
+  }
 };
 
 struct mfx_plan {
@@ -88,6 +157,11 @@ struct mfx_plan {
   void* dxs = nullptr;
   void* doffs = nullptr;
   void* dsscr = nullptr;
+  void* dstatus = nullptr;   // int[4]: [0] flag word the fit kernels OR into (MFX_ST_*), read by mfx_plan_status
+  ~mfx_plan() {
+    (void)hipFree(dg); (void)hipFree(dslo); (void)hipFree(dshi); (void)hipFree(dtG); (void)hipFree(ddG);
+    (void)hipFree(dtab32s); (void)hipFree(dxs); (void)hipFree(doffs); (void)hipFree(dsscr); (void)hipFree(dstatus);
+  }
 };
 
 static int require_device(int device) {
@@ -121,7 +195,7 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
       }
     }
   }
-  mfx_tables* t = new mfx_tables();
+  std::unique_ptr<mfx_tables> t(new mfx_tables());
   t->device = device;
   t->h_x.assign(knots_x, knots_x + P);
   t->h_G.assign(G_un, G_un + S);
@@ -157,18 +231,13 @@ extern "C" int mfx_tables_create(const double* knots_x, const int32_t* shell_off
   t->d.tab = (const double2*)t->dtab;
   t->d.tab32 = (const float2*)t->dtab32;
   t->d.G_un = (const double*)t->dG;
-  *out = t;
+  *out = t.release();
   return MFX_OK;
 }
 
 extern "C" void mfx_tables_destroy(mfx_tables* t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
-  (void)hipFree(t->dx);
-  (void)hipFree(t->doff);
-  (void)hipFree(t->dtab);
-  (void)hipFree(t->dtab32);
-  (void)hipFree(t->dG);
   delete t;
 }
 extern "C" int mfx_tables_num_atoms(const mfx_tables* t) { return t ? t->d.N : 0; }
@@ -176,9 +245,12 @@ extern "C" int mfx_tables_num_atoms(const mfx_tables* t) { return t ? t->d.N : 0
 static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g, const std::vector<int>& slo,
                        const std::vector<int>& shi, const std::vector<double>& tG, const std::vector<double>& dG,
                        mfx_plan** out) {
-  mfx_plan* p = new mfx_plan();
+  std::unique_ptr<mfx_plan> p(new mfx_plan());
   p->t = t;
   HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMalloc(&p->dstatus, 4 * sizeof(int)));
+  HIPCHK(hipMemset(p->dstatus, 0, 4 * sizeof(int)));
+  p->d.status = (int*)p->dstatus;
   HIPCHK(hipMalloc(&p->dg, sizeof(double) * 3 * M));
   HIPCHK(hipMalloc(&p->dslo, sizeof(int) * M));
   HIPCHK(hipMalloc(&p->dshi, sizeof(int) * M));
@@ -272,7 +344,7 @@ static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g,
     p->d.tab32s = (const float2*)p->dtab32s; p->d.xs = (const double*)p->dxs;
     p->d.offs = (const int*)p->doffs; p->d.s_scr = (const int*)p->dsscr;
   }
-  *out = p;
+  *out = p.release();
   return MFX_OK;
 }
 
@@ -319,206 +391,83 @@ extern "C" int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs
 extern "C" void mfx_plan_destroy(mfx_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->t->device);
-  (void)hipFree(p->dg);
-  (void)hipFree(p->dslo);
-  (void)hipFree(p->dshi);
-  (void)hipFree(p->dtG);
-  (void)hipFree(p->ddG);
-  (void)hipFree(p->dtab32s); (void)hipFree(p->dxs); (void)hipFree(p->doffs); (void)hipFree(p->dsscr);
   delete p;
 }
 
+// Deferred error channel of the asynchronous "_dev" entry points: waits for `stream`, then reports (and clears) what
+// the fit kernels flagged since the last call.  MFX_ERR_DIR_NORM: a voxel's fascicle direction failed the reference's
+// unit-norm check (mf_utils.py:1798-1802; the reference raises ValueError from inside the voxel loop).
+extern "C" int mfx_plan_status(const mfx_plan* p, void* stream) {
+  if (!p) return fail(MFX_ERR_ARG, "mfx_plan_status: null plan");
+  if (int rc = require_device(p->t->device)) return rc;
+  int st[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(st, p->dstatus, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (st[0] == 0) return MFX_OK;
+  HIPCHK(hipMemsetAsync(p->dstatus, 0, sizeof(st), (hipStream_t)stream));
+  if (st[0] & MFX_ST_DIR_NORM)
+    return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm (voxel %d of the batch).", st[1]);
+  return fail(MFX_ERR_HIP, "fit kernels reported status 0x%x", st[0]);
+}
+
 // ---------------------------------------------------------------------------------------------
-// kernel dispatch
-static size_t k2_lds_bytes(int ksteps, bool bracket, int NP, int tiles, int nbuf) {
-  const size_t MP = (size_t)ksteps * 4;
-  const size_t MPS = (MP + 15) / 16 * 16;
-  size_t dbl = (size_t)nbuf * tiles * MPS * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 6 * (size_t)NP + 32;
-  size_t bytes = dbl * 8 + sizeof(Cand) * MFX_MAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
-  return bytes;
-}
-
-static unsigned long long* g_stamps = nullptr;
-extern "C" void mfx_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
-static int g_k2_pipe = -1;  // MFX_K2_PIPE=0 selects the un-pipelined chunk loop (A/B measurements)
-static int g_k2_maxc = MFX_MAXC;
-extern "C" void mfx_debug_set_k2_maxc(int maxc) { g_k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
-static int g_k2s_nb = 0;    // 0: as many chunk images as fit; 2: force the two-image schedule
-extern "C" void mfx_debug_set_k2s_images(int nb) { g_k2s_nb = (nb == 2) ? 2 : 0; }
-static int g_k2s_cap = 0;   // 0: MFX_S_CAP
-extern "C" void mfx_debug_set_k2s_cap(int cap) {
-  int c = 4;
-  while (2 * c <= cap) c *= 2;   // a power of two
-  g_k2s_cap = (cap <= 0 || c >= MFX_S_CAP) ? 0 : c;
-}
-
-template <int KSTEPS, bool BRACKET, bool PIPE = true, int NW = 8, int TILES = 2, int NBUF = 2>
-static int launch_k2_t(const FitK2Args& a, int nvox, hipStream_t st) {
-  if (g_k2_pipe < 0) { const char* e = getenv("MFX_K2_PIPE"); g_k2_pipe = (e && e[0] == '0') ? 0 : 1; }
-  if constexpr (PIPE && !BRACKET) { if (!g_k2_pipe) return launch_k2_t<KSTEPS, BRACKET, false, NW, TILES, NBUF>(a, nvox, st); }
-  const size_t lds = k2_lds_bytes(KSTEPS, BRACKET, a.T.ldn, TILES, NBUF);
-  if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2 kernel needs %zu B of LDS (> 160 KiB): N=%d too large", lds, a.T.N);
-  auto kern = mfx_fit_k2_kernel<KSTEPS, BRACKET, PIPE && !BRACKET, NW, TILES, NBUF>;
-  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (g_profiling) {
-    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
-    HIPCHK(hipEventRecord(g_ev0, st));
-  }
-  FitK2Args aa = a;
-  aa.stamps = g_stamps;
-  aa.maxc = g_k2_maxc;
-  hipLaunchKernelGGL(kern, dim3(nvox), dim3(NW * 64), lds, st, aa);
-  HIPCHK(hipGetLastError());
-  if (g_profiling) {
-    HIPCHK(hipEventRecord(g_ev1, st));
-    g_ev_launches = 1;
-    g_ev_valid = true;
-  }
-  return MFX_OK;
-}
-
-static int launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st) {
-  const int M = a.P.M;
-  const bool br = a.P.any_bracket != 0;
-  if (M <= 64) return br ? launch_k2_t<16, true>(a, nvox, st) : launch_k2_t<16, false>(a, nvox, st);
-  if (M <= 200) {
-    if (k2_lds_bytes(50, br, a.T.ldn, 2, 2) <= 160 * 1024) return br ? launch_k2_t<50, true>(a, nvox, st) : launch_k2_t<50, false>(a, nvox, st);
-    // large dictionaries (N > 960): the single-tile single-buffer form, one wave per SIMD
-    return br ? launch_k2_t<50, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<50, false, false, 4, 1, 1>(a, nvox, st);
-  }
-  // long protocols: one wave per SIMD (512 registers hold the A operand), single-tile single-buffer chunks
-  if (M <= 400) return br ? launch_k2_t<100, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<100, false, false, 4, 1, 1>(a, nvox, st);
-  if (M <= 560) return br ? launch_k2_t<140, true, false, 4, 1, 1>(a, nvox, st) : launch_k2_t<140, false, false, 4, 1, 1>(a, nvox, st);
-  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernel supports M <= 560 (got %d)", M);
-}
-
-// ---- split-FP16 screening kernel (fit_k2s.hip) for exact-G protocols, FP64 kernel for what it hands back
-static size_t k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
+// kernel dispatch (the launchers of the K=2 kernel families live in their own translation units: mfx_host.h)
+size_t mfx_k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
   return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP + 4 * 8 * 64 +
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
-static int g_k2_screen = -1;   // MFX_K2_SCREEN=0 disables the screening kernel (A/B measurements)
-static thread_local int g_last_fallback = 0;
-extern "C" int mfx_debug_last_fallback_count(void) { return g_last_fallback; }
-extern "C" void mfx_debug_set_k2_screen(int enabled) { g_k2_screen = enabled ? 1 : 0; }
-
-template <int KS, bool BR, int NB>
-static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
-  const size_t lds = k2s_lds_bytes(KS, a.T.N, BR, NB);
-  auto kern = mfx_fit_k2s_kernel<KS, BR, NB>;
-  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  struct StreamMem {   // stream-ordered allocation released on every exit path
-    void* p = nullptr;
-    hipStream_t s;
-    explicit StreamMem(hipStream_t s_) : s(s_) {}
-    ~StreamMem() { if (p) (void)hipFreeAsync(p, s); }
-  } fbm(st);
-  HIPCHK(hipMallocAsync(&fbm.p, sizeof(int) * ((size_t)nvox + 1), st));
-  int* fb = (int*)fbm.p;   // [0] count, [1..] voxel list
-  HIPCHK(hipMemsetAsync(fb, 0, sizeof(int), st));
-  if (g_profiling) {
-    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
-    HIPCHK(hipEventRecord(g_ev0, st));
-  }
-  FitK2Args aa = a;
-  aa.stamps = g_stamps;
-  aa.fb_count = fb;
-  aa.fb_list = fb + 1;
-  aa.scap = g_k2s_cap ? g_k2s_cap : MFX_S_CAP;
-  hipLaunchKernelGGL(kern, dim3(nvox), dim3(512), lds, st, aa);
-  HIPCHK(hipGetLastError());
-  if (g_profiling) HIPCHK(hipEventRecord(g_ev1, st));
-  int nfb = 0;
-  HIPCHK(hipMemcpyAsync(&nfb, fb, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  g_last_fallback = nfb;
-  int rc = MFX_OK;
-  if (nfb > 0) {           // voxels whose short list overflowed: redo them with the FP64 kernel
-    const bool prof = g_profiling;
-    g_profiling = false;   // keep the event pair of the screening kernel
-    FitK2Args ab = a;
-    ab.vox_list = fb + 1;
-    rc = launch_k2_f64(ab, nfb, st);
-    g_profiling = prof;
-  }
-  if (g_profiling) { g_ev_launches = 1; g_ev_valid = true; }
-  return rc;
-}
-
-// whether launch_k2_f64 can serve this plan: the screening kernel hands voxels back to it, so it runs only then
-static bool k2_f64_fits(const FitK2Args& a) {
-  const int M = a.P.M;
-  const bool br = a.P.any_bracket != 0;
-  if (M > 560) return false;
-  const size_t lds = M <= 64 ? k2_lds_bytes(16, br, a.T.ldn, 2, 2) : M <= 200 ? k2_lds_bytes(50, br, a.T.ldn, 1, 1)
-                   : M <= 400 ? k2_lds_bytes(100, br, a.T.ldn, 1, 1) : k2_lds_bytes(140, br, a.T.ldn, 1, 1);
-  return lds <= 160 * 1024;
-}
 
 static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
-  if (g_k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); g_k2_screen = (e && e[0] == '0') ? 0 : 1; }
+  MfxThread& T = mfx_thread();
+  if (T.k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); T.k2_screen = (e && e[0] == '0') ? 0 : 1; }
   const int M = a.P.M;
   const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
-  if (g_k2_screen && M <= 256 && k2_f64_fits(a)) {
+  if (T.k2_screen && M <= 256 && mfx_k2_f64_fits(a)) {
     const bool br = a.P.any_bracket != 0;
     // three chunk images (one barrier per chunk) where they fit into the 160 KB of LDS, else two
-    const int NB = (g_k2s_nb != 2 && k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);
-#define MFX_K2S_CASE(KS_, BR_, NB_) if (KSm == KS_ && br == BR_ && NB == NB_) return launch_k2s_t<KS_, BR_, NB_>(a, nvox, st)
-    MFX_K2S_CASE(4, false, 3);  MFX_K2S_CASE(4, true, 3);
-    MFX_K2S_CASE(8, false, 3);  MFX_K2S_CASE(8, true, 3);
-    MFX_K2S_CASE(13, false, 3); MFX_K2S_CASE(13, true, 3);
-    MFX_K2S_CASE(4, false, 2);  MFX_K2S_CASE(4, true, 2);
-    MFX_K2S_CASE(8, false, 2);  MFX_K2S_CASE(8, true, 2);
-    MFX_K2S_CASE(13, false, 2); MFX_K2S_CASE(13, true, 2);
-    MFX_K2S_CASE(16, false, 2); MFX_K2S_CASE(16, true, 2);
-    MFX_K2S_CASE(16, false, 3); MFX_K2S_CASE(16, true, 3);
-#undef MFX_K2S_CASE
+    const int NB = (T.k2s_nb != 2 && mfx_k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (mfx_k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);
+    if (NB) {
+      if (KSm == 4) return mfx_launch_k2s_ks4(a, nvox, st, br, NB);
+      if (KSm == 8) return mfx_launch_k2s_ks8(a, nvox, st, br, NB);
+      if (KSm == 13) return mfx_launch_k2s_ks13(a, nvox, st, br, NB);
+      return mfx_launch_k2s_ks16(a, nvox, st, br, NB);
+    }
   }
-  return launch_k2_f64(a, nvox, st);
+  if (int rc = mfx_launch_k2_f64(a, nvox, st, true)) return rc;
+  return MFX_OK;
 }
 
-// ---- extra (voxel-independent) columns of one voxel class: [csf] + [ear_0..ear_{E-1}]
+// ---- extra (voxel-independent) columns of one voxel class: [csf] + [ear_0..ear_{E-1}], built on the device in
+// stream order (mfx_extras_kernel) from DEVICE copies of sig_csf / sig_ear; released in stream order too
 struct ExtrasHost {
   ExtrasDev d{};
   void* dx = nullptr;
   void* dG = nullptr;
-  int build(int M, int has_csf, int E, const double* sig_csf, const double* sig_ear, bool src_on_device) {
+  hipStream_t st = nullptr;
+  ExtrasHost() = default;
+  ExtrasHost(const ExtrasHost&) = delete;
+  ExtrasHost& operator=(const ExtrasHost&) = delete;
+  int build(int M, int has_csf, int E, const double* d_sig_csf, const double* d_sig_ear, hipStream_t stream) {
     const int NX = has_csf + E;
+    st = stream;
     d.NX = NX; d.has_csf = has_csf; d.E = E; d.x = nullptr; d.Gxx = nullptr;
     if (NX == 0) return MFX_OK;
     if (NX > MFX_NXMAX) return fail(MFX_ERR_UNSUPPORTED, "at most %d CSF+EAR columns are supported (got %d)", MFX_NXMAX, NX);
-    std::vector<double> hc(has_csf ? M : 0), he((size_t)M * E);
-    if (has_csf) {
-      if (!sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
-      if (src_on_device) HIPCHK(hipMemcpy(hc.data(), sig_csf, sizeof(double) * M, hipMemcpyDeviceToHost));
-      else std::memcpy(hc.data(), sig_csf, sizeof(double) * M);
-    }
-    if (E) {
-      if (!sig_ear) return fail(MFX_ERR_ARG, "sig_ear missing");
-      if (src_on_device) HIPCHK(hipMemcpy(he.data(), sig_ear, sizeof(double) * M * E, hipMemcpyDeviceToHost));
-      else std::memcpy(he.data(), sig_ear, sizeof(double) * (size_t)M * E);
-    }
-    std::vector<double> x((size_t)M * NX), G((size_t)NX * NX, 0.0);
-    for (int m = 0; m < M; ++m) {
-      if (has_csf) x[(size_t)m * NX] = hc[m];
-      for (int e = 0; e < E; ++e) x[(size_t)m * NX + has_csf + e] = he[(size_t)m * E + e];
-    }
-    for (int p = 0; p < NX; ++p)
-      for (int q = 0; q < NX; ++q) {
-        double acc = 0.0;  // sequential over rows, as the reference's Gram loops (mf_utils.py:311-319, 517-531)
-        for (int m = 0; m < M; ++m) acc += x[(size_t)m * NX + p] * x[(size_t)m * NX + q];
-        G[(size_t)p * NX + q] = acc;
-      }
-    HIPCHK(hipMalloc(&dx, sizeof(double) * x.size()));
-    HIPCHK(hipMalloc(&dG, sizeof(double) * G.size()));
-    HIPCHK(hipMemcpy(dx, x.data(), sizeof(double) * x.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dG, G.data(), sizeof(double) * G.size(), hipMemcpyHostToDevice));
+    if (has_csf && !d_sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
+    if (E && !d_sig_ear) return fail(MFX_ERR_ARG, "sig_ear missing");
+    HIPCHK(hipMallocAsync(&dx, sizeof(double) * (size_t)M * NX, st));
+    HIPCHK(hipMallocAsync(&dG, sizeof(double) * (size_t)NX * NX, st));
+    hipLaunchKernelGGL(mfx_extras_kernel, dim3(1), dim3(256), 0, st, d_sig_csf, d_sig_ear, M, has_csf, E, (double*)dx, (double*)dG);
+    HIPCHK(hipGetLastError());
     d.x = (const double*)dx;
     d.Gxx = (const double*)dG;
     return MFX_OK;
   }
-  ~ExtrasHost() { (void)hipFree(dx); (void)hipFree(dG); }
+  ~ExtrasHost() {
+    if (dx) (void)hipFreeAsync(dx, st);
+    if (dG) (void)hipFreeAsync(dG, st);
+  }
 };
 
 static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
@@ -526,6 +475,7 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   const size_t lds = sizeof(double) * (3 * (size_t)M + MFX_NXMAX + 8 + MFX_SWG + 3 * MFX_SWG) + sizeof(long) * MFX_SWG +
                      sizeof(int) * 2 * (size_t)M;
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "too many measurements (%d)", M);
+  if (int rc = mfx_prof_begin(st)) return rc;
   if (a.P.any_bracket) {
     HIPCHK(hipFuncSetAttribute((const void*)mfx_fit_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mfx_fit_small_kernel<true>, dim3(nvox), dim3(MFX_SWG), lds, st, a);
@@ -534,46 +484,7 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
     hipLaunchKernelGGL(mfx_fit_small_kernel<false>, dim3(nvox), dim3(MFX_SWG), lds, st, a);
   }
   HIPCHK(hipGetLastError());
-  return MFX_OK;
-}
-
-static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf, int NX) {
-  const size_t MP = (size_t)ksteps * 4;
-  size_t dbl = (size_t)nbuf * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + (size_t)nw * 16 * MFX_XS +
-               MFX_XS + (size_t)(nw + 2) * 16 * (NX + 1) +
-               2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 32;
-  return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
-}
-
-template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
-static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
-  const size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, a.X.NX);
-  if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
-  auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF>;
-  HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // per-workgroup scratch slab: launch in chunks so the slab stays modest
-  const int chunk = 2048;
-  const size_t slab = (size_t)2 * a.T.ldn * MFX_XS;
-  double* ws = nullptr;
-  HIPCHK(hipMallocAsync((void**)&ws, sizeof(double) * slab * std::min(chunk, nvox), st));
-  a.ws = ws;
-  for (int base = 0; base < nvox; base += chunk) {
-    a.vox_base = base;
-    hipLaunchKernelGGL(kern, dim3(std::min(chunk, nvox - base)), dim3(NW * 64), lds, st, a);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipFreeAsync(ws, st));
-  return MFX_OK;
-}
-
-static int launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
-  const int M = a.P.M;
-  const bool br = a.P.any_bracket != 0;
-  if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
-  if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
-  if (M <= 400) return br ? launch_k2x_t<100, true, 4, 1>(a, nvox, st) : launch_k2x_t<100, false, 4, 1>(a, nvox, st);
-  if (M <= 560) return br ? launch_k2x_t<140, true, 4, 1>(a, nvox, st) : launch_k2x_t<140, false, 4, 1>(a, nvox, st);
-  return fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernels support M <= 560 (got %d)", M);
+  return mfx_prof_end(st);
 }
 
 // one homogeneous voxel class (every voxel: K fascicles, has_csf, has_ear); device pointers
@@ -603,7 +514,7 @@ static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_p
     a.T = p->t->d; a.P = p->d; a.X = X.d;
     a.Y = d_Y; a.peaks = d_peaks; a.peaks_ld = peaks_ld; a.vox_list = d_list;
     a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc; a.csf_on = csf_on; a.ear_on = ear_on;
-    return launch_k2x(a, nvox, st);
+    return mfx_launch_k2x(a, nvox, st);
   }
   return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented", K, has_csf, has_ear);
 }
@@ -613,77 +524,150 @@ extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const dou
                                  double* d_params_out, void* stream) {
   if (!p || !d_Y || !d_params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: bad argument");
   if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (maxfasc > 0 && !d_peaks) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: d_peaks is null but maxfasc = %d", maxfasc);
   if (V == 0) return MFX_OK;
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
   if (int rc = require_device(p->t->device)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = mfx_fb_begin(st)) return rc;
   ExtrasHost X;
-  if (int rc = X.build(p->d.M, csf_on ? 1 : 0, ear_on ? E : 0, d_sig_csf, d_sig_ear, true)) return rc;
-  return fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
-                       csf_on ? 1 : 0, ear_on ? 1 : 0, d_params_out, (hipStream_t)stream);
+  if (int rc = X.build(p->d.M, csf_on ? 1 : 0, ear_on ? E : 0, d_sig_csf, d_sig_ear, st)) return rc;
+  if (int rc = fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
+                             csf_on ? 1 : 0, ear_on ? 1 : 0, d_params_out, st)) return rc;
+  return mfx_fb_end(st);
 }
 
-extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,
-                             const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
-                             const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {
+// ---- host-buffer voxel loop: pinned staging + chunked H2D on a copy stream overlapped with the kernels on a compute
+// stream (reference loop: mf.py:976-1032).  `rows` (optional) fuses the reference's mask gather `data[mask > 0]`
+// (mf.py:644, 1020-1022) into the staging copy: voxel v's signal is the M doubles at Y + rows[v] * M.
+static int pipe_setup(int device, size_t want_bytes) {
+  MfxThread& T = mfx_thread();
+  if (T.pipe_device != device) {
+    for (int q = 0; q < 2; ++q) { if (T.stage[q]) (void)hipHostFree(T.stage[q]); T.stage[q] = nullptr; }
+    T.stage_bytes = 0;
+    if (T.s_copy) (void)hipStreamDestroy(T.s_copy);
+    if (T.s_comp) (void)hipStreamDestroy(T.s_comp);
+    T.s_copy = T.s_comp = nullptr;
+    for (int q = 0; q < 2; ++q) { if (T.ev_h2d[q]) (void)hipEventDestroy(T.ev_h2d[q]); T.ev_h2d[q] = nullptr; }
+    HIPCHK(hipStreamCreateWithFlags(&T.s_copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&T.s_comp, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&T.ev_h2d[q], hipEventDisableTiming));
+    T.pipe_device = device;
+  }
+  if (T.stage_bytes < want_bytes) {
+    for (int q = 0; q < 2; ++q) { if (T.stage[q]) (void)hipHostFree(T.stage[q]); T.stage[q] = nullptr; }
+    T.stage_bytes = 0;
+    for (int q = 0; q < 2; ++q) HIPCHK(hipHostMalloc(&T.stage[q], want_bytes, hipHostMallocDefault));
+    T.stage_bytes = want_bytes;
+  }
+  return MFX_OK;
+}
+
+extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K,
+                                  const uint8_t* csf, const uint8_t* ear, const double* peaks, int maxfasc, int csf_on,
+                                  int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
+                                  double* params_out) {
   if (!p || !Y || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
   if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (maxfasc > 0 && !peaks) return fail(MFX_ERR_ARG, "mfx_fit_batch: peaks is null but maxfasc = %d", maxfasc);
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large");
   if (int rc = require_device(p->t->device)) return rc;
   csf_on = csf_on ? 1 : 0;
   ear_on = ear_on ? 1 : 0;
   const int M = p->d.M;
   const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
-  std::memset(params_out, 0, sizeof(double) * (size_t)V * num_params);
   if (V == 0) return MFX_OK;
-  // bin voxels by class (K, csf, ear); direction check once per batch (the reference checks per
-  // voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
-  std::vector<int> cls[12];
-  for (int64_t v = 0; v < V; ++v) {
-    const int k = K[v];
-    if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
-    const int c = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
-    if ((c && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
-    for (int f = 0; f < k; ++f) {
-      const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
-      const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-      if (!(std::fabs(1 - nrm) <= 1e-3))
-        return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
+  // chunks of ~32 MB of signal; per chunk the voxels are binned by class (K, csf, ear); the direction check runs once
+  // per batch on the host (the reference checks per voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
+  const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, ((int64_t)32 << 20) / ((int64_t)M * 8)));
+  const int64_t nch = (V + CH - 1) / CH;
+  std::vector<int> list((size_t)V);              // voxel lists, chunk-major then class-major
+  std::vector<int> cnt((size_t)nch * 12, 0);
+  {
+    std::vector<uint8_t> cls((size_t)V);
+    for (int64_t v = 0; v < V; ++v) {
+      const int k = K[v];
+      if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
+      const int c = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
+      if ((c && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
+      for (int f = 0; f < k; ++f) {
+        const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
+        const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (!(std::fabs(1 - nrm) <= 1e-3))
+          return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
+      }
+      cls[(size_t)v] = (uint8_t)(k * 4 + c * 2 + e);
+      ++cnt[(size_t)(v / CH) * 12 + cls[(size_t)v]];
     }
-    cls[k * 4 + c * 2 + e].push_back((int)v);
+    std::vector<size_t> pos((size_t)nch * 12);
+    size_t acc = 0;
+    for (size_t q = 0; q < pos.size(); ++q) { pos[q] = acc; acc += (size_t)cnt[q]; }
+    for (int64_t v = 0; v < V; ++v) list[pos[(size_t)(v / CH) * 12 + cls[(size_t)v]]++] = (int)v;
   }
-  double *dY = nullptr, *dpk = nullptr, *dpar = nullptr;
-  int* dlist = nullptr;
-  HIPCHK(hipMalloc(&dY, sizeof(double) * (size_t)V * M));
-  HIPCHK(hipMalloc(&dpk, sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1)));
-  HIPCHK(hipMalloc(&dpar, sizeof(double) * (size_t)V * num_params));
-  HIPCHK(hipMalloc(&dlist, sizeof(int) * (size_t)V));
-  HIPCHK(hipMemcpy(dY, Y, sizeof(double) * (size_t)V * M, hipMemcpyHostToDevice));
-  if (maxfasc > 0) HIPCHK(hipMemcpy(dpk, peaks, sizeof(double) * (size_t)V * 3 * maxfasc, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(dpar, 0, sizeof(double) * (size_t)V * num_params));
-  int rc = MFX_OK;
-  size_t off = 0;
-  std::vector<ExtrasHost> xs(4);
-  for (int ce = 0; ce < 4 && rc == MFX_OK; ++ce) {
-    if (((ce >> 1) && !csf_on) || ((ce & 1) && !ear_on)) continue;  // class cannot occur
-    rc = xs[ce].build(M, ce >> 1, (ce & 1) ? E : 0, sig_csf, sig_ear, false);
-  }
-  for (int c = 0; c < 12 && rc == MFX_OK; ++c) {
-    if (cls[c].empty()) continue;
-    HIPCHK(hipMemcpy(dlist + off, cls[c].data(), sizeof(int) * cls[c].size(), hipMemcpyHostToDevice));
-    rc = fit_class_dev(p, dY, dpk, 3 * maxfasc, dlist + off, (int)cls[c].size(), c >> 2, (c >> 1) & 1, c & 1, xs[c & 3],
-                       maxfasc, csf_on, ear_on, dpar, nullptr);
-    off += cls[c].size();
-  }
-  if (rc == MFX_OK) {
-    hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(e));
-  }
-  if (rc == MFX_OK) {
-    hipError_t e = hipMemcpy(params_out, dpar, sizeof(double) * (size_t)V * num_params, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(MFX_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(dY); (void)hipFree(dpk); (void)hipFree(dpar); (void)hipFree(dlist);
+  if (int rc = pipe_setup(p->t->device, (size_t)CH * M * sizeof(double))) return rc;
+  MfxThread& T = mfx_thread();
+  DevMem dY, dpk, dpar, dlist, dsc, dse;
+  HIPCHK(dY.alloc(sizeof(double) * (size_t)V * M));
+  HIPCHK(dpk.alloc(sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1)));
+  HIPCHK(dpar.alloc(sizeof(double) * (size_t)V * num_params));
+  HIPCHK(dlist.alloc(sizeof(int) * (size_t)V));
+  // everything below is stream-ordered; any failure drains both streams before the buffers above are released
+  auto run = [&]() -> int {
+    if (maxfasc > 0) HIPCHK(hipMemcpyAsync(dpk.p, peaks, sizeof(double) * (size_t)V * 3 * maxfasc, hipMemcpyHostToDevice, T.s_comp));
+    HIPCHK(hipMemcpyAsync(dlist.p, list.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, T.s_comp));
+    HIPCHK(hipMemsetAsync(dpar.p, 0, sizeof(double) * (size_t)V * num_params, T.s_comp));
+    if (csf_on) {
+      if (!sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
+      HIPCHK(dsc.alloc(sizeof(double) * M));
+      HIPCHK(hipMemcpyAsync(dsc.p, sig_csf, sizeof(double) * M, hipMemcpyHostToDevice, T.s_comp));
+    }
+    if (ear_on) {
+      if (!sig_ear || E < 1) return fail(MFX_ERR_ARG, "sig_ear missing");
+      HIPCHK(dse.alloc(sizeof(double) * (size_t)M * E));
+      HIPCHK(hipMemcpyAsync(dse.p, sig_ear, sizeof(double) * (size_t)M * E, hipMemcpyHostToDevice, T.s_comp));
+    }
+    if (int rc = mfx_fb_begin(T.s_comp)) return rc;
+    ExtrasHost xs[4];
+    for (int ce = 0; ce < 4; ++ce) {
+      if (((ce >> 1) && !csf_on) || ((ce & 1) && !ear_on)) continue;  // class cannot occur
+      if (int rc = xs[ce].build(M, ce >> 1, (ce & 1) ? E : 0, dsc.as<double>(), dse.as<double>(), T.s_comp)) return rc;
+    }
+    size_t off = 0;
+    for (int64_t c = 0; c < nch; ++c) {
+      const int64_t v0 = c * CH, nv = std::min<int64_t>(CH, V - v0);
+      double* stg = (double*)T.stage[c & 1];
+      if (c >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[c & 1]));   // the copy that last used this staging buffer is done
+      if (rows) {
+        for (int64_t v = 0; v < nv; ++v) std::memcpy(stg + (size_t)v * M, Y + (size_t)rows[v0 + v] * M, sizeof(double) * M);
+      } else {
+        std::memcpy(stg, Y + (size_t)v0 * M, sizeof(double) * (size_t)nv * M);
+      }
+      HIPCHK(hipMemcpyAsync(dY.as<double>() + (size_t)v0 * M, stg, sizeof(double) * (size_t)nv * M, hipMemcpyHostToDevice, T.s_copy));
+      HIPCHK(hipEventRecord(T.ev_h2d[c & 1], T.s_copy));
+      HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[c & 1], 0));
+      for (int q = 0; q < 12; ++q) {
+        const int n = cnt[(size_t)c * 12 + q];
+        if (!n) continue;
+        if (int rc = fit_class_dev(p, dY.as<double>(), dpk.as<double>(), 3 * maxfasc, dlist.as<int>() + off, n, q >> 2, (q >> 1) & 1,
+                                   q & 1, xs[q & 3], maxfasc, csf_on, ear_on, dpar.as<double>(), T.s_comp)) return rc;
+        off += (size_t)n;
+      }
+    }
+    if (int rc = mfx_fb_end(T.s_comp)) return rc;
+    HIPCHK(hipMemcpyAsync(params_out, dpar.p, sizeof(double) * (size_t)V * num_params, hipMemcpyDeviceToHost, T.s_comp));
+    return MFX_OK;
+  };
+  int rc = run();
+  const hipError_t e1 = hipStreamSynchronize(T.s_copy), e2 = hipStreamSynchronize(T.s_comp);
+  if (rc == MFX_OK && (e1 != hipSuccess || e2 != hipSuccess))
+    rc = fail(MFX_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return rc;
+}
+
+extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,
+                             const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
+                             const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {
+  return mfx_fit_batch_rows(p, Y, nullptr, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf, sig_ear, E, V, params_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -766,7 +750,12 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
   if (!A || !dicsizes || !y || !w || !sub || !tot || !min_obj || !y_rec || M < 1 || Kp < 1)
     return fail(MFX_ERR_ARG, "mfx_solve_exhaustive: bad argument");
   if (Kp > MFX_GK) return fail(MFX_ERR_UNSUPPORTED, "at most %d sub-dictionaries are supported (got %d)", MFX_GK, Kp);
-  if (int rc = require_device(0)) return rc;
+  {   // runs on the calling thread's current device
+    int dev = 0;
+    if (mfx_device_count() <= 0) return fail(MFX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    HIPCHK(hipGetDevice(&dev));
+    if (int rc = require_device(dev)) return rc;
+  }
   SolveArgs a{};
   long Ntot = 0, ntup = 1;
   for (int k = 0; k < Kp; ++k) {
@@ -825,14 +814,6 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
 
 // ---------------------------------------------------------------------------------------------
 // Monte-Carlo signal synthesis from spin phases (mf_utils.py:2758-2810)
-namespace {
-struct DevMem {   // frees on scope exit
-  void* p = nullptr;
-  ~DevMem() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-  template <class T> T* as() const { return (T*)p; }
-};
-}  // namespace
 
 extern "C" int mfx_monte_carlo_average_dev(const double* d_phases, int64_t n_entries, int64_t spin_stride,
                                            int64_t dim_stride, int dim, const int64_t* delta_mapping,
@@ -886,17 +867,10 @@ extern "C" int mfx_monte_carlo_average_dev(const double* d_phases, int64_t n_ent
   HIPCHK(hipMemcpyAsync(dord.p, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
   a.tile_first = dfirst.as<int>(); a.tile_cnt = dcnt.as<int>(); a.tile_start = dstart.as<long>();
   a.gs = dgs.as<double>(); a.order = dord.as<int>(); a.partial = dpart.as<double>(); a.signal = dsig.as<double>();
-  if (g_profiling) {
-    if (!g_ev0) { HIPCHK(hipEventCreate(&g_ev0)); HIPCHK(hipEventCreate(&g_ev1)); }
-    HIPCHK(hipEventRecord(g_ev0, st));
-  }
+  if (int rc = mfx_prof_begin(st)) return rc;
   hipLaunchKernelGGL(mfx_mc_partial_kernel, dim3((unsigned)nblocks), dim3(MFX_MC_THREADS), 0, st, a);
   HIPCHK(hipGetLastError());
-  if (g_profiling) {
-    HIPCHK(hipEventRecord(g_ev1, st));
-    g_ev_launches = 1;
-    g_ev_valid = true;
-  }
+  if (int rc = mfx_prof_end(st)) return rc;
   hipLaunchKernelGGL(mfx_mc_finalize_kernel, dim3((unsigned)n_seq), dim3(64), 0, st, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(signal, dsig.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, st));

@@ -39,7 +39,21 @@ struct PlanDev {
   const double* xs;      // knot value per row of tab32s (bracketed plans only)
   const int* offs;       // [n_shells][2] first row, knot count of the table shells followed by the virtual shells
   const int* s_scr;      // [M] shell of the row in (xs, offs)
+  // deferred error channel of the asynchronous entry points (mfx_plan_status): [0] flag word, [1] a flagged voxel
+  int* status;
 };
+
+#define MFX_ST_DIR_NORM 1   // a fascicle direction failed |1 - |d|| <= 1e-3 (mf_utils.py:1798-1802)
+
+// the reference's per-voxel direction check (interp_PGSE_from_multishell, mf_utils.py:1798-1802), once per voxel and
+// fascicle: flags the plan's status word instead of raising (the device cannot), the voxel is still computed
+__device__ __forceinline__ void mfx_check_dir(const PlanDev& P, const double* __restrict__ pk, int vox) {
+  const double nrm = sqrt((pk[0] * pk[0] + pk[1] * pk[1]) + pk[2] * pk[2]);
+  if (!(fabs(1.0 - nrm) <= 1e-3) && P.status) {
+    atomicOr(P.status, MFX_ST_DIR_NORM);
+    P.status[1] = vox;
+  }
+}
 
 // per-(direction,row) evaluation descriptor: which knot interval, and the offset inside it
 struct RowDesc {

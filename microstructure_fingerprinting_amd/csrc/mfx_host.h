@@ -1,0 +1,101 @@
+// mfx_host.h -- host-side plumbing shared by the translation units of libmfx.so.
+//
+// The library is built from several translation units so that the kernel families compile in parallel
+// (mfx_api.hip: C ABI, tables/plans, small kernels; tu_k2.hip: FP64 two-fascicle kernel; tu_k2s_*.hip: the
+// screening kernel's instantiations; tu_k2x.hip: two fascicles + CSF/EAR).  Everything mutable that is not owned
+// by a handle lives in ONE thread-local record: one host thread drives one GPU (mf.py:_fit_sharded), so the error
+// string, the timing events and the diagnostic switches of a thread never meet those of another.
+#pragma once
+#include "../../include/mfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "fit_k2.hip"
+#include "fit_k2x.hip"
+
+struct MfxThread {
+  std::string err;
+  // timing hook (mfx_set_profiling / mfx_last_kernel_ms)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int ev_launches = 0;
+  bool ev_valid = false;
+  bool profiling = false;
+  // diagnostics (mfx_debug_*)
+  unsigned long long* stamps = nullptr;
+  int k2_pipe = -1;        // MFX_K2_PIPE=0 selects the un-pipelined chunk loop of the FP64 kernel
+  int k2_maxc = MFX_MAXC;  // FP64 kernel: short-list size beyond which its exhaustive exact pass runs
+  int k2x_maxc = MFX_XMAXC;
+  int k2s_nb = 0;          // 0: as many chunk images as fit; 2: force the two-image schedule
+  int k2s_cap = 0;         // 0: MFX_S_CAP
+  int k2_screen = -1;      // MFX_K2_SCREEN=0 disables the screening kernels
+  // hand-back counters of the last mfx_fit_batch* call: summed on the device over its launches, copied to pinned memory
+  // behind the kernels and read only when somebody asks (mfx_debug_last_*_count): the _dev entry points never synchronise
+  int* fb_dev = nullptr;           // device [4]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
+  int* fb_host = nullptr;          // pinned [4]
+  int fb_device = -1;              // device fb_dev lives on
+  hipEvent_t fb_event = nullptr;
+  bool fb_pending = false;
+  // host pipeline of mfx_fit_batch (pinned staging, copy/compute streams), created on first use per device
+  void* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  hipStream_t s_copy = nullptr, s_comp = nullptr;
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+  int pipe_device = -1;
+};
+
+MfxThread& mfx_thread();
+int mfx_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) return mfx_fail(MFX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
+  } while (0)
+
+// device allocation released on every exit path
+struct DevMem {
+  void* p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  void* release() { void* q = p; p = nullptr; return q; }
+  template <class T> T* as() const { return (T*)p; }
+};
+// stream-ordered allocation released (in stream order) on every exit path
+struct StreamMem {
+  void* p = nullptr;
+  hipStream_t s;
+  explicit StreamMem(hipStream_t s_) : s(s_) {}
+  StreamMem(const StreamMem&) = delete;
+  StreamMem& operator=(const StreamMem&) = delete;
+  ~StreamMem() { if (p) (void)hipFreeAsync(p, s); }
+  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, s); }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+// event pair around the dominant kernel of a class launch (bench.py reads it through mfx_last_kernel_ms)
+int mfx_prof_begin(hipStream_t st);
+int mfx_prof_end(hipStream_t st);
+// hand-back counters: zero the call's totals / add one launch's device counters [n <= 4 ints] / queue their copy to
+// pinned memory, all in stream order behind the work on `st` (no host synchronisation)
+int mfx_fb_begin(hipStream_t st);
+int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st);
+int mfx_fb_end(hipStream_t st);
+
+// ---- kernel launchers, one translation unit each
+// FP64 two-fascicle kernel (tu_k2.hip).  With a.list_count set, a.vox_list is a device-side list whose length only the
+// device knows: the launch covers nvox blocks and those beyond *a.list_count exit at once.
+int mfx_launch_k2_f64(const FitK2Args& a, int nvox, hipStream_t st, bool record_events);
+bool mfx_k2_f64_fits(const FitK2Args& a);
+// screening kernel (tu_k2s_*.hip): KS k-steps of 16 measurements, bracketed protocol or not, NB chunk images
+size_t mfx_k2s_lds_bytes(int KS, int N, bool bracket, int NB);
+int mfx_launch_k2s_ks4(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
+int mfx_launch_k2s_ks8(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
+int mfx_launch_k2s_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
+int mfx_launch_k2s_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
+// two fascicles + CSF/EAR (tu_k2x.hip)
+int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st);

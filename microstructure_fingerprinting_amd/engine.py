@@ -79,13 +79,27 @@ def num_params(maxfasc, csf_on, ear_on):
     return 1 + 2 * maxfasc + int(csf_on) + 2 * int(ear_on) + 2   # mf.py:381
 
 
-def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0):
-    """Host-buffer voxel loop (mfx_fit_batch): returns params_in_mask [V x num_params] (mf.py:1018-1028)."""
+def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0, rows=None):
+    """Host-buffer voxel loop (mfx_fit_batch_rows): returns params_in_mask [V x num_params] (mf.py:1018-1028).
+
+    ``rows`` (int64 [V], optional): voxel v's signal is ``Y[rows[v]]`` -- the ROI gather ``data[mask > 0]`` of the
+    reference (mf.py:644) done by the library while it stages the upload; Y then is the whole [n_vox_total x M] volume."""
     Y = L.f64c(Y)
-    V, M = Y.shape
+    if Y.ndim != 2:
+        raise ValueError("Y should be a 2-D array [voxels x measurements]")
+    M = Y.shape[1]
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        V = rows.shape[0]
+        if V and (rows.min() < 0 or rows.max() >= Y.shape[0]):
+            raise ValueError("rows out of range")
+    else:
+        V = Y.shape[0]
     if M != plan.M:
         raise ValueError("data has %d measurements, protocol has %d" % (M, plan.M))
     K = np.ascontiguousarray(K, dtype=np.int32)
+    if K.shape[0] != V:
+        raise ValueError("K should have one entry per voxel")
     csf_a = np.ascontiguousarray(csf, dtype=np.uint8) if csf is not None else np.zeros(V, np.uint8)
     ear_a = np.ascontiguousarray(ear, dtype=np.uint8) if ear is not None else np.zeros(V, np.uint8)
     pk = L.f64c(peaks).reshape(V, -1) if maxfasc > 0 else np.zeros((V, 3))
@@ -94,10 +108,38 @@ def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None
     out = np.zeros((V, num_params(maxfasc, csf_on, ear_on)))
     sc = L.f64c(sig_csf) if sig_csf is not None else None
     se = L.f64c(sig_ear) if sig_ear is not None else None
-    L.check(L.lib().mfx_fit_batch(plan.handle(), L.dptr(Y), L.iptr(K), L.bptr(csf_a), L.bptr(ear_a), L.dptr(pk),
-                                  int(maxfasc), int(csf_on), int(ear_on),
-                                  L.dptr(sc) if sc is not None else None, L.dptr(se) if se is not None else None,
-                                  int(E), V, L.dptr(out)))
+    L.check(L.lib().mfx_fit_batch_rows(plan.handle(), L.dptr(Y), L.lptr(rows) if rows is not None else None, L.iptr(K),
+                                       L.bptr(csf_a), L.bptr(ear_a), L.dptr(pk), int(maxfasc), int(csf_on), int(ear_on),
+                                       L.dptr(sc) if sc is not None else None, L.dptr(se) if se is not None else None,
+                                       int(E), V, L.dptr(out)))
+    return out
+
+
+def fit_batch_dev(plan, d_Y, d_peaks, maxfasc, csf_on=False, ear_on=False, d_sig_csf=None, d_sig_ear=None, E=0,
+                  out=None, check=True):
+    """Device-resident voxel loop (mfx_fit_batch_dev) on torch CUDA tensors of ONE voxel class (every voxel:
+    K == maxfasc, csf == csf_on, ear == ear_on).  Enqueues on torch's current stream and returns the [V x num_params]
+    output tensor without waiting; ``check=True`` then waits and raises what the kernels flagged (a fascicle
+    direction that is not a unit vector: the reference's per-voxel ValueError, mf_utils.py:1798-1802)."""
+    import torch
+    assert d_Y.is_cuda and d_Y.dtype == torch.float64 and d_Y.is_contiguous()
+    V = d_Y.shape[0]
+    if d_Y.shape[1] != plan.M:
+        raise ValueError("data has %d measurements, protocol has %d" % (d_Y.shape[1], plan.M))
+    if maxfasc > 0:
+        assert d_peaks.is_cuda and d_peaks.dtype == torch.float64 and d_peaks.is_contiguous()
+        if tuple(d_peaks.shape) != (V, 3 * maxfasc):
+            raise ValueError("peaks should have shape (%d, %d)" % (V, 3 * maxfasc))
+    if out is None:
+        out = torch.zeros((V, num_params(maxfasc, csf_on, ear_on)), dtype=torch.float64, device=d_Y.device)
+    st = torch.cuda.current_stream(d_Y.device).cuda_stream
+    L.check(L.lib().mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_peaks.data_ptr() if maxfasc > 0 else None,
+                                      int(maxfasc), int(bool(csf_on)), int(bool(ear_on)),
+                                      d_sig_csf.data_ptr() if d_sig_csf is not None else None,
+                                      d_sig_ear.data_ptr() if d_sig_ear is not None else None, int(E), V,
+                                      out.data_ptr(), st))
+    if check:
+        L.check(L.lib().mfx_plan_status(plan.handle(), st))
     return out
 
 

@@ -295,18 +295,33 @@ class MFModel():
         if data_arr.shape[-1] != num_seq:
             raise ValueError("Data has %d measurements per voxel but the protocol has %d." % (data_arr.shape[-1],
                                                                                                 num_seq))
+        # ---- what the reference checks in every voxel with a fascicle, through interp_PGSE_from_multishell
+        # (mf_utils.py:1786-1789 and 1804-1807), checked once per fit here: the protocol's timing must be the
+        # dictionary's, its gradient directions zero or unit vectors
+        if maxfasc > 0:
+            if not np.all(np.isclose(self.ms_interpolator['scheme_DeldelTE'], pgse_scheme[:, 4:7])):
+                raise ValueError("Delta, delta and TE values should all be identical to those in the multi-shell "
+                                 "sampling.")
+            mfu._check_gnorms(pgse_scheme)
         # ---- the voxel loop, batched on the device (replaces ref:976-1032)
-        Y = np.ascontiguousarray(data_arr[roi], dtype=np.float64)     # ROI order == np.where(mask > 0)
+        # ROI order == np.where(mask > 0).  A float64 C-contiguous volume is handed over as it is with the ROI's row
+        # numbers: the library gathers the rows while it stages the upload (the reference's data[mask > 0], ref:644)
+        if isinstance(data_arr, np.ndarray) and data_arr.dtype == np.float64 and data_arr.flags.c_contiguous:
+            Y = data_arr.reshape(-1, num_seq)
+            rows = np.flatnonzero(roi.reshape(-1)).astype(np.int64)
+        else:
+            Y = np.ascontiguousarray(data_arr[roi], dtype=np.float64)
+            rows = None
         st = time.time()
         if VRB >= 2:
             print("Starting estimation in %d voxel(s) on the GPU%s." % (ROI_size, "s (sharded)" if parallel else ""))
         args = (numfasc_roi, csf_mask, ear_mask, peaks_roi, maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear)
         ndev = L.lib().mfx_device_count()
         if parallel and ndev > 1 and ROI_size >= 2 * ndev:
-            params_in_mask = self._fit_sharded(pgse_scheme, Y, args, ndev)
+            params_in_mask = self._fit_sharded(pgse_scheme, Y, rows, args, ndev)
         else:
             plan = self.ms_interpolator.plan_for(pgse_scheme)
-            params_in_mask = engine.fit_batch(plan, Y, *args)
+            params_in_mask = engine.fit_batch(plan, Y, *args, rows=rows)
         if VRB >= 2:
             print("Estimation performed in %g second(s)." % (time.time() - st))
         fitinfo = {'maxfasc': maxfasc, 'csf_on': csf_on, 'ear_on': ear_on, 'affine': nii_affine, 'mask': mask_arr,
@@ -331,22 +346,25 @@ class MFModel():
                              % (name, " ".join("%d" % x for x in img_shape), " ".join("%d" % x for x in m.shape)))
         return (m[roi] > 0), aff
 
-    def _fit_sharded(self, pgse_scheme, Y, args, ndev):
-        """parallel=True: contiguous ROI shards, one host thread per GPU (ctypes releases the GIL); each
-        device gets its own copy of the tables.  (Multi-process / multi-node runs use dist.py.)"""
+    def _fit_sharded(self, pgse_scheme, Y, rows, args, ndev):
+        """parallel=True: one host thread per GPU (ctypes releases the GIL), each device with its own copy of the
+        tables.  The voxels of every class (numfasc, CSF, EAR: their cost differs by up to 40x) are dealt round-robin
+        over the devices so that each gets the same mix (reference: mp.Pool over voxels, ref:978-1009).
+        (Multi-process / multi-node runs use dist.py.)"""
         numfasc_roi, csf_mask, ear_mask, peaks_roi, maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear = args
-        V = Y.shape[0]
+        V = numfasc_roi.shape[0]
         out = [None] * ndev
+        idx = [mdist.balanced_shard_indices(numfasc_roi, csf_mask, ear_mask, d, ndev) for d in range(ndev)]
         errs = []
 
         def work(d):
             try:
-                lo, hi = mdist.shard_range(V, d, ndev)
+                ix = idx[d]
                 ms = mfu.MultiShellInterpolator(self.ms_interpolator['scheme_DeldelTE'], self.ms_interpolator['Gms_un'],
                                                 self.ms_interpolator['interpolators'], device=d)
-                out[d] = engine.fit_batch(ms.plan_for(pgse_scheme), Y[lo:hi], numfasc_roi[lo:hi], csf_mask[lo:hi],
-                                          ear_mask[lo:hi], peaks_roi[lo:hi], maxfasc, csf_on, ear_on, sig_csf, sig_ear,
-                                          num_ear)
+                out[d] = engine.fit_batch(ms.plan_for(pgse_scheme), Y, numfasc_roi[ix], csf_mask[ix], ear_mask[ix],
+                                          peaks_roi[ix], maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear,
+                                          rows=(ix if rows is None else rows[ix]))
             except Exception as e:   # re-raised below, like pool.get() (ref:1006-1008)
                 errs.append(e)
         th = [threading.Thread(target=work, args=(d,)) for d in range(ndev)]
@@ -354,7 +372,10 @@ class MFModel():
         [t.join() for t in th]
         if errs:
             raise errs[0]
-        return np.concatenate(out, axis=0)
+        full = np.zeros((V, out[0].shape[1]))
+        for d in range(ndev):
+            full[idx[d]] = out[d]
+        return full
 
 
 class MFModelFit():

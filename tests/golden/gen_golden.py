@@ -503,15 +503,79 @@ def gen_mc(mfu):
     print("mc_cases.npz written", out["sig_direct"][:4], out["sig_files_bdouble"][:4])
 
 
+def gen_real(mfu, mfmod, part=None):
+    """The real dictionaries held by the reference's own tests, stored as DATA (arrays only), plus a few voxels fitted
+    by the reference itself at full dictionary size:
+      * UKBB 90-direction dictionary (271 x 986 atoms, 10 EAR columns; near-duplicate atoms) with the protocol of
+        subject 1000521 (105 rows, 9 distinct G values against 4 table shells -> G-bracketing) ->
+        real_ukbb.npz; reference fits: 4 voxels K=2, 1 voxel K=2+CSF (_3), 1 voxel K=2+CSF+EAR (_4up) -> real_ukbb_fits.npz
+      * HCP-MGH dictionary (552 x 782) and its scheme with 40 b0 rows (test_hcp_dict's inputs) -> real_hcp.npz
+    The reference's pure-Python kernels take minutes per voxel here; `part` = "data" | "k2" | "k2csf" | "k2csfear"."""
+    uk = mfu.loadmat(os.path.join(FIX, "ukbb_90_dirs_dictionary_hcp_deltas.mat"))
+    subj = mfu.loadmat(os.path.join(FIX, "1000521_dictionary_hcp_deltas.mat"))
+    sch_subj = np.ascontiguousarray(subj["sch_mat"], dtype=float)
+    model = {"dictionary": np.ascontiguousarray(uk["dictionary"], dtype=float), "sch_mat": np.asarray(uk["sch_mat"], float),
+             "orientation": np.asarray(uk["orientation"], float), "num_atom": int(uk["Nsubs"]), "num_ear": int(uk["Near"]),
+             "T2_csf": float(uk["T2_csf"]), "DIFF_csf": float(uk["CSF_DIFF"]), "T2_ear": float(uk["T2_ear"]),
+             "DIFF_ear": np.asarray(uk["Dear"], float), "fasc_propnames": ["rad", "fin"],
+             "rad": np.asarray(uk["rad"], float), "fin": np.asarray(uk["fin"], float)}
+    if part in (None, "data"):
+        np.savez_compressed(os.path.join(OUT, "real_ukbb.npz"), sch_subj=sch_subj,
+                            **{k: np.asarray(v) for k, v in model.items() if k != "fasc_propnames"})
+        hcp = mfu.loadmat(os.path.join(FIX, "MC_dictionary_hcp.mat"))
+        sch = mfu.import_PGSE_scheme(os.path.join(FIX, "hcp_mgh_1003.scheme1"))
+        nb0 = 40
+        sch_b0 = np.vstack((np.zeros((nb0, sch.shape[1])), sch))
+        sch_b0[:nb0, 4:] = sch[0, 4:]
+        np.savez_compressed(os.path.join(OUT, "real_hcp.npz"), dictionary=np.asarray(hcp["dic_fascicle_refdir"], float),
+                            S0=np.asarray(hcp["S0_fascicle"], float), sch_mat=sch_b0, sig_csf=np.asarray(hcp["sig_csf"], float),
+                            WM_DIFF=np.float64(hcp["WM_DIFF"]), CSF_DIFF=np.float64(hcp["CSF_DIFF"]))
+        print("real_ukbb.npz, real_hcp.npz written")
+    cases = {"k2": (4, 0, 0, 101), "k2csf": (1, 1, 0, 102), "k2csfear": (1, 1, 1, 103)}
+    for name, (V, c, e, seed) in cases.items():
+        if part not in (None, name):
+            continue
+        rng = np.random.default_rng(seed)
+        ms = mfu.init_PGSE_multishell_interp(model["dictionary"], model["sch_mat"], model["orientation"])
+        N = model["num_atom"]
+        peaks = np.concatenate([unit(rng, V), unit(rng, V)], axis=1)
+        atoms = rng.integers(0, N, (V, 2))
+        gam = mfu.get_gyromagnetic_ratio('H')
+        b = (gam * sch_subj[:, 3] * sch_subj[:, 5]) ** 2 * (sch_subj[:, 4] - sch_subj[:, 5] / 3)
+        sig_csf = np.exp(-sch_subj[:, 6] / model["T2_csf"]) * np.exp(-b * model["DIFF_csf"])
+        sig_ear = np.stack([np.exp(-sch_subj[:, 6] / model["T2_ear"]) * np.exp(-b * D) for D in model["DIFF_ear"]], axis=1)
+        Y = np.zeros((V, sch_subj.shape[0]))
+        for v in range(V):
+            nu = rng.dirichlet(np.ones(2 + c + e))
+            for k in range(2):
+                Dk = mfu.interp_PGSE_from_multishell(sch_subj, peaks[v, 3 * k:3 * k + 3], msinterp=ms)
+                Y[v] += 500.0 * nu[k] * Dk[:, atoms[v, k]]
+            if c:
+                Y[v] += 500.0 * nu[2] * sig_csf
+            if e:
+                Y[v] += 500.0 * nu[2 + c] * sig_ear[:, int(rng.integers(0, model["num_ear"]))]
+        Y += rng.normal(0, 500.0 / 30.0, Y.shape)
+        mask = np.ones(V, dtype=int)
+        m = mfmod.MFModel(model)
+        fit = m.fit(Y, mask, 2, peaks=peaks, pgse_scheme=sch_subj, csf_mask=(mask if c else None),
+                    ear_mask=(mask if e else None), verbose=0)
+        out = {"Y": Y, "peaks": peaks, "csf": np.int64(c), "ear": np.int64(e), "param_names": np.array(fit.param_names)}
+        for pn in fit.param_names:
+            out["map_" + pn] = np.asarray(getattr(fit, pn))
+        np.savez_compressed(os.path.join(OUT, "real_ukbb_fit_%s.npz" % name), **out)
+        print("real_ukbb_fit_%s.npz written" % name)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--part", default=None, help="gen_real only: data | k2 | k2csf | k2csfear")
     a = ap.parse_args()
     mfu, mfmod = import_reference()
     todo = {"solver": lambda: gen_solver(mfu), "rotation": lambda: gen_rotation(mfu),
             "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod),
             "inputs": lambda: gen_inputs(mfu, mfmod), "cleanup": lambda: gen_cleanup(mfu, mfmod),
-            "mc": lambda: gen_mc(mfu)}
+            "mc": lambda: gen_mc(mfu), "real": lambda: gen_real(mfu, mfmod, a.part)}
     for k, fn in todo.items():
         if a.only in (None, k):
             fn()

@@ -157,3 +157,27 @@ def test_fit_from_tensors_and_colat_matches_reference():
     assert fit.param_names == list(d["c_names"])
     for name in fit.param_names:
         assert np.allclose(getattr(fit, name), d["c_" + name], rtol=1e-5, atol=1e-12), name
+
+
+def test_fit_checks_protocol_timing_and_gradient_norms():
+    """What the reference raises from inside every voxel with a fascicle (interp_PGSE_from_multishell,
+    mf_utils.py:1786-1789 and 1804-1807) is raised once per fit: a protocol whose Delta/delta/TE differ from the
+    dictionary's, and gradient directions that are neither zero nor unit vectors.  No GPU needed: both are argument
+    errors found before the device is touched."""
+    from microstructure_fingerprinting_amd import mf, synth
+    rng = np.random.default_rng(3)
+    sch = synth.make_scheme(rng, 2, [1000, 2000], [12, 12])
+    N = 10
+    model = {"dictionary": synth.make_dictionary(rng, sch, N), "sch_mat": sch, "orientation": np.array([0.0, 0.0, 1.0]),
+             "num_atom": N, "num_ear": 2, "T2_csf": 2.0, "DIFF_csf": 3e-9, "T2_ear": 0.08, "DIFF_ear": np.array([0.3e-9, 0.9e-9]),
+             "fasc_propnames": ["rad"], "rad": np.linspace(1e-6, 2e-6, N)}
+    m = mf.MFModel(model)
+    V = 4
+    Y = rng.uniform(1, 2, (V, sch.shape[0]))
+    pk = synth.unit_vectors(rng, V)
+    bad = sch.copy(); bad[:, 4] *= 1.1                     # other Delta
+    with pytest.raises(ValueError, match="Delta, delta and TE"):
+        m.fit(Y, np.ones(V, int), 1, peaks=pk, pgse_scheme=bad, verbose=0)
+    bad = sch.copy(); bad[5, :3] *= 1.5                    # not a unit vector
+    with pytest.raises(ValueError, match="zero or unit norm"):
+        m.fit(Y, np.ones(V, int), 1, peaks=pk, pgse_scheme=bad, verbose=0)

@@ -1,0 +1,357 @@
+"""Oracle-refereed parity at FULL dictionary size, in the regimes that stress the kernels' short lists.
+
+The fused kernels rank in reduced precision (fit_k2s: split-FP16 MFMA) or through feasible-support scores
+(fit_k2x) and decide on a short list in the reference's arithmetic; these tests let the CPU oracle -- not another
+HIP kernel -- referee them where that matters:
+  * >= 2400 config-2 voxels (782 atoms x 200 measurements) from the regimes of tools/dev_regimes.py;
+  * the reference tests' own real dictionaries (tests/golden/real_*.npz: UKBB 271 x 986 with near-duplicate atoms and a
+    G-bracketed subject protocol, through MFModel.fit; HCP-MGH 552 x 782 through rotate_atom tables);
+  * config 4 ([782, 782, 1, 10]) at full size incl. noise-free and pure-CSF voxels, and the flood cases of the
+    two-fascicle + CSF/EAR kernel at small size.
+Bar: atom indices bit-exact, weights within 1e-5 relative (north_star); the kernels in fact reproduce the oracle to
+the last bits for _1/_2/_3 and to ~1e-9 for _4up (third-party Lawson-Hanson arithmetic in the reference).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+Z = np.array([0.0, 0.0, 1.0])
+NTHREADS = max(1, min(os.cpu_count() or 1, 64))
+
+
+def _tables(ms):
+    return {"S": ms.S, "N": ms.num_subs, "G_un": ms.Gms_un, "off": ms.off, "x": ms.x_flat, "Y": ms.Y_flat,
+            "scheme_DeldelTE": ms["scheme_DeldelTE"]}
+
+
+def _rotate_cols(plan, dirs, cols):
+    """[B, M] rotated single atoms through the library's host entry point (signal synthesis for the tests)."""
+    from microstructure_fingerprinting_amd import _lib as L
+    dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    out = np.zeros((dirs.shape[0], plan.M))
+    L.check(L.lib().mfx_rotate_cols(plan.handle(), L.dptr(dirs), L.iptr(cols), dirs.shape[0], 0, L.dptr(out)))
+    return out
+
+
+def _second_peak(rng, p1, deg):
+    r = rng.standard_normal(p1.shape)
+    r -= (r * p1).sum(1, keepdims=True) * p1
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    a = np.deg2rad(deg)
+    p2 = np.cos(a) * p1 + np.sin(a) * r
+    return p2 / np.linalg.norm(p2, axis=1, keepdims=True)
+
+
+def _assert_rows(got, ref, maxfasc, what, rtol=1e-5):
+    ids = slice(1 + maxfasc, 1 + 2 * maxfasc)
+    bad = np.where(np.any(got[:, ids] != ref[:, ids], axis=1))[0]
+    assert bad.size == 0, "%s: atom indices differ from the oracle in voxels %s (got %s, oracle %s)" % (
+        what, bad[:8], got[bad[:3], ids], ref[bad[:3], ids])
+    assert np.allclose(got, ref, rtol=rtol, atol=1e-9), "%s: parameters differ from the oracle" % what
+    return float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-300) * (np.abs(ref) > 1e-6)))
+
+
+REGIMES = [  # name, snr (0: noise-free), crossing angle in degrees (None: random), nu0 (None: Dirichlet)
+    ("snr30", 30, None, None), ("snr10", 10, None, None), ("snr100", 100, None, None), ("noise_free", 0, None, None),
+    ("cross15", 30, 15.0, None), ("cross3", 30, 3.0, None), ("cross0.2", 30, 0.2, None), ("identical", 30, 0.0, None),
+    ("nu95", 30, None, 0.95), ("one_fascicle", 30, None, 1.0), ("one_fascicle_noise_free", 0, None, 1.0),
+    ("second_only", 30, None, 0.0),
+]
+
+
+def test_k2_stress_regimes_vs_oracle_full_size():
+    """2400 voxels at BASELINE config 2's size (782 atoms x 200 measurements) from twelve regimes, screening kernel
+    (the default path) against the CPU oracle: one dominant fascicle, nu = (0.95, 0.05), crossings of 0.2 / 3 / 15
+    degrees, identical peaks, noise-free data, SNR 10 / 30 / 100.  Every row must agree."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    sch, dic, rng = synth.make_model("C2")
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    N, M = ms.num_subs, sch.shape[0]
+    per = 200
+    pk, Ys, names = [], [], []
+    for name, snr, deg, nu0 in REGIMES:
+        p1 = synth.unit_vectors(rng, per)
+        p2 = synth.unit_vectors(rng, per) if deg is None else (p1.copy() if deg == 0.0 else _second_peak(rng, p1, deg))
+        atoms = rng.integers(0, N, (per, 2))
+        nu = rng.dirichlet(np.ones(2), per) if nu0 is None else np.tile([nu0, 1.0 - nu0], (per, 1))
+        Y = 500.0 * nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + 500.0 * nu[:, 1:] * _rotate_cols(plan, p2, atoms[:, 1])
+        if snr:
+            Y = Y + rng.normal(0, 500.0 / snr, Y.shape)
+        pk.append(np.concatenate([p1, p2], axis=1)); Ys.append(Y); names += [name] * per
+    peaks, Y = np.concatenate(pk), np.concatenate(Ys)
+    V = Y.shape[0]
+    assert V >= 2000
+    dev = torch.device("cuda", 0)
+    lib = L.lib()
+    lib.mfx_debug_set_k2_screen(1)
+    out = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2)
+    got = out.cpu().numpy()
+    nfb, ngd = lib.mfx_debug_last_fallback_count(), lib.mfx_debug_last_guard_count()
+    z = np.zeros(V, bool)
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0, nthreads=NTHREADS)
+    names = np.array(names)
+    for name, *_ in REGIMES:
+        sel = names == name
+        _assert_rows(got[sel], ref[sel], 2, "regime %s" % name)
+    assert np.array_equal(got[:, 3:5], ref[:, 3:5])
+    print("stress regimes: %d voxels, ids exact, max rel err %.2e, handed back %d (guard %d)"
+          % (V, float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-300) * (np.abs(ref) > 1e-6))), nfb, ngd))
+    assert nfb < 0.05 * V
+
+
+def _ukbb_model():
+    d = np.load(os.path.join(G, "real_ukbb.npz"))
+    model = {k: d[k] for k in d.files if k != "sch_subj"}
+    for k in ("num_atom", "num_ear"):
+        model[k] = int(model[k])
+    for k in ("T2_csf", "DIFF_csf", "T2_ear"):
+        model[k] = float(model[k])
+    model["fasc_propnames"] = ["rad", "fin"]
+    return model, np.ascontiguousarray(d["sch_subj"])
+
+
+def test_ukbb_real_dictionary_through_mfmodel_vs_oracle():
+    """The reference tests' UKBB dictionary (271 x 986 atoms, near-duplicate atoms, 10 EAR columns) with subject
+    1000521's protocol (105 rows, G-bracketed) through MFModel.fit: 640 two-fascicle voxels + 32 with CSF (reference
+    _3) + 8 with CSF and EAR (_4up), incl. voxels generated from the dictionary's most similar atom pairs, against the
+    oracle; and the voxels the reference itself fitted (tests/golden/real_ukbb_fit_*.npz)."""
+    from microstructure_fingerprinting_amd import mf, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    model, sch = _ukbb_model()
+    m = mf.MFModel(model)
+    ms = m.ms_interpolator
+    plan = ms.plan_for(sch)
+    N, M, E = model["num_atom"], sch.shape[0], model["num_ear"]
+    rng = np.random.default_rng(5)
+    # the most similar atom pairs of the canonical dictionary (cosine closest to 1)
+    D = model["dictionary"] / np.linalg.norm(model["dictionary"], axis=0)
+    C = D.T @ D
+    np.fill_diagonal(C, 0.0)
+    twins = np.argsort(C.max(axis=1))[::-1][:64]
+    nK2, nC, nCE = 640, 32, 8
+    V = nK2 + nC + nCE
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    p2[:40] = _second_peak(rng, p1[:40], 2.0)
+    p2[40:60] = p1[40:60]
+    atoms = rng.integers(0, N, (V, 2))
+    atoms[60:124, 0] = twins                      # a twin atom in fascicle 0 ...
+    atoms[124:188, 1] = twins                     # ... in fascicle 1
+    csf = np.zeros(V, bool); csf[nK2:] = True
+    ear = np.zeros(V, bool); ear[nK2 + nC:] = True
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / model["T2_csf"]) * np.exp(-b * model["DIFF_csf"])
+    sig_ear = np.stack([np.exp(-sch[:, 6] / model["T2_ear"]) * np.exp(-b * Dk) for Dk in model["DIFF_ear"]], axis=1)
+    nu = rng.dirichlet(np.ones(4), V)
+    nu[:, 2] *= csf; nu[:, 3] *= ear
+    nu[188:220, 1] = 0.0                          # one fascicle only
+    nu /= nu.sum(1, keepdims=True)
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:2] * _rotate_cols(plan, p2, atoms[:, 1])
+                 + nu[:, 2:3] * sig_csf + nu[:, 3:4] * sig_ear[:, rng.integers(0, E, V)].T)
+    Y += rng.normal(0, 500.0 / 30.0, Y.shape)
+    peaks = np.concatenate([p1, p2], axis=1)
+    mask = np.ones(V, dtype=int)
+    fit = m.fit(Y, mask, 2, peaks=peaks, pgse_scheme=sch, csf_mask=csf.astype(int), ear_mask=ear.astype(int), verbose=0)
+    got = fit.params_in_mask
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), csf, ear, peaks, 2, True, True, sig_csf, sig_ear, E,
+                        nthreads=NTHREADS)
+    _assert_rows(got[:nK2], ref[:nK2], 2, "UKBB K=2")
+    _assert_rows(got[nK2:nK2 + nC], ref[nK2:nK2 + nC], 2, "UKBB K=2+CSF")
+    _assert_rows(got[nK2 + nC:], ref[nK2 + nC:], 2, "UKBB K=2+CSF+EAR")
+    assert np.array_equal(got[:, 7], ref[:, 7])   # EAR atom
+    # voxels fitted by the reference itself
+    for name in ("k2", "k2csf", "k2csfear"):
+        fn = os.path.join(G, "real_ukbb_fit_%s.npz" % name)
+        if not os.path.exists(fn):
+            continue
+        c = np.load(fn)
+        Vr = c["Y"].shape[0]
+        one = np.ones(Vr, dtype=int)
+        f = m.fit(c["Y"], one, 2, peaks=c["peaks"], pgse_scheme=sch, csf_mask=(one if int(c["csf"]) else None),
+                  ear_mask=(one if int(c["ear"]) else None), verbose=0)
+        for pn in c["param_names"]:
+            a, r = np.asarray(getattr(f, str(pn))), c["map_" + str(pn)]
+            assert np.allclose(a, r, rtol=1e-5, atol=1e-12), "reference golden %s: map %s differs" % (name, pn)
+
+
+def test_hcp_real_dictionary_long_protocol_vs_oracle():
+    """The reference's HCP-MGH dictionary (552 rows x 782 atoms: test_hcp_dict's shape of use) as a dense dictionary
+    fitted on its own 552-row protocol: two-fascicle voxels against the oracle (M = 552 > 256: the long-protocol path)."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    d = np.load(os.path.join(G, "real_hcp.npz"))
+    sch, dic = np.ascontiguousarray(d["sch_mat"]), np.ascontiguousarray(d["dictionary"])
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    N = ms.num_subs
+    rng = np.random.default_rng(9)
+    V = 96
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    p2[:8] = _second_peak(rng, p1[:8], 3.0)
+    atoms = rng.integers(0, N, (V, 2))
+    atoms[8:16] = 86                               # the atom the reference's own test recovers
+    nu = rng.dirichlet(np.ones(2), V)
+    nu[16:24] = [1.0, 0.0]
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:] * _rotate_cols(plan, p2, atoms[:, 1]))
+    Y += rng.normal(0, 500.0 / 30.0, Y.shape)
+    Y[24:32] = 500.0 * (nu[24:32, :1] * _rotate_cols(plan, p1[24:32], atoms[24:32, 0]) + nu[24:32, 1:] * _rotate_cols(plan, p2[24:32], atoms[24:32, 1]))
+    peaks = np.concatenate([p1, p2], axis=1)
+    got = engine.fit_batch(plan, Y, np.full(V, 2), None, None, peaks, 2, False, False)
+    z = np.zeros(V, bool)
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "HCP 552 x 782")
+
+
+def _c4_model(N, E, rng=None):
+    from microstructure_fingerprinting_amd import synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    sch, dic, rng = synth.make_model("C2", N=N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3.0e-9)
+    sig_ear = np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * Dk) for Dk in np.linspace(0.2e-9, 1.2e-9, E)], axis=1)
+    return sch, ms, sig_csf, sig_ear, rng
+
+
+def _flood_voxels(rng, plan, N, E, sig_csf, sig_ear, V):
+    """Voxels whose optimum leaves a fascicle atom (or both) inactive: every tuple sharing the active atoms ties."""
+    from microstructure_fingerprinting_amd import synth
+    M = plan.M
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(4), V)              # f0, f1, csf, ear
+    kind = np.arange(V) % 8
+    nu[kind == 0] = [0, 0, 1, 0]                   # pure CSF
+    nu[kind == 1, 1] = 0                           # fascicle 0 + CSF + EAR only
+    nu[kind == 2, 0] = 0                           # fascicle 1 + ...
+    nu[kind == 3, 2:] = 0                          # no CSF / EAR signal although the columns are offered
+    nu[kind == 4] = [0, 0, 0, 1]                   # pure EAR
+    p2[kind == 5] = p1[kind == 5]                  # identical peaks
+    nu /= nu.sum(1, keepdims=True)
+    e_id = rng.integers(0, E, V)
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:2] * _rotate_cols(plan, p2, atoms[:, 1])
+                 + nu[:, 2:3] * sig_csf + nu[:, 3:4] * sig_ear[:, e_id].T)
+    noise = rng.normal(0, 500.0 / 30.0, (V, M))
+    noise[kind == 6] = 0.0                         # noise-free
+    nf_csf = (kind == 0) & (np.arange(V) % 16 == 0)
+    noise[nf_csf] = 0.0                            # noise-free pure CSF: EVERY tuple ties -> the exhaustive pass is the answer
+    return np.concatenate([p1, p2], axis=1), Y + noise, int(nf_csf.sum())
+
+
+@pytest.mark.parametrize("c,e", [(1, 0), (0, 1), (1, 1)])
+def test_k2x_flood_voxels_vs_oracle(c, e):
+    """Two fascicles + CSF and/or EAR at N = 64, E = 4 on voxels whose optimum has inactive atoms (pure CSF / EAR, one
+    fascicle, noise-free, identical peaks): the ties used to flood the 256-entry short list, which dropped entries
+    silently; now the families are evaluated exactly.  Only a voxel in which EVERY tuple ties (noise-free pure CSF) may
+    need the exhaustive last resort."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine
+    from oracle import oracle as orc
+    N, E, V = 64, 4, 64
+    sch, ms, sig_csf, sig_ear, rng = _c4_model(N, E)
+    plan = ms.plan_for(sch)
+    peaks, Y, n_all_tie = _flood_voxels(rng, plan, N, E, sig_csf * c, sig_ear * e, V)
+    one = np.ones(V, bool)
+    got = engine.fit_batch(plan, Y, np.full(V, 2), one * c, one * e, peaks, 2, bool(c), bool(e), sig_csf if c else None,
+                           sig_ear if e else None, E if e else 0)
+    nfb = L.lib().mfx_debug_last_fallback_count()
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one * c, one * e, peaks, 2, bool(c), bool(e),
+                        sig_csf if c else None, sig_ear if e else None, E if e else 0, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "flood voxels csf=%d ear=%d" % (c, e), rtol=1e-5 if (c and e) else 1e-9)
+    assert nfb <= n_all_tie, "exhaustive pass taken by %d voxels" % nfb
+
+
+def test_k2x_exhaustive_last_resort():
+    """A short list that overflows (forced by a zero cap) must trigger the exhaustive exact pass, never a silent drop."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine
+    from oracle import oracle as orc
+    N, E, V = 40, 3, 12
+    sch, ms, sig_csf, sig_ear, rng = _c4_model(N, E)
+    plan = ms.plan_for(sch)
+    peaks, Y, _ = _flood_voxels(rng, plan, N, E, sig_csf, sig_ear, V)
+    one = np.ones(V, bool)
+    lib = L.lib()
+    try:
+        lib.mfx_debug_set_k2x_maxc(0)
+        got = engine.fit_batch(plan, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E)
+        nfb = lib.mfx_debug_last_fallback_count()
+    finally:
+        lib.mfx_debug_set_k2x_maxc(-1)
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "exhaustive pass")
+    assert nfb == V
+
+
+def test_c4_full_size_vs_oracle():
+    """BASELINE config 4 at full size: sub-dictionaries [782, 782, 1, 10], 200 measurements (reference _4up: one NNLS
+    per tuple, 6.1e6 tuples per voxel -> tens of seconds per voxel for the oracle, one voxel per host thread), and the
+    two _3 classes [782, 782, 1] / [782, 782, 10]; incl. noise-free and pure-CSF voxels."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine
+    from oracle import oracle as orc
+    N, E = 782, 10
+    sch, ms, sig_csf, sig_ear, rng = _c4_model(N, E)
+    plan = ms.plan_for(sch)
+    V = max(8, min(NTHREADS, 16))
+    peaks, Y, n_all_tie = _flood_voxels(rng, plan, N, E, sig_csf, sig_ear, V)
+    one = np.ones(V, bool)
+    got = engine.fit_batch(plan, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E)
+    nfb = L.lib().mfx_debug_last_fallback_count()
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "config 4")
+    assert np.array_equal(got[:, 7], ref[:, 7]), "EAR atom differs"
+    assert nfb <= n_all_tie
+    for c, e in ((1, 0), (0, 1)):
+        pk2, Y2, _ = _flood_voxels(rng, plan, N, E, sig_csf * c, sig_ear * e, V)
+        g2 = engine.fit_batch(plan, Y2, np.full(V, 2), one * c, one * e, pk2, 2, bool(c), bool(e), sig_csf if c else None,
+                              sig_ear if e else None, E if e else 0)
+        r2 = orc.fit_batch(_tables(ms), sch, Y2, np.full(V, 2), one * c, one * e, pk2, 2, bool(c), bool(e),
+                           sig_csf if c else None, sig_ear if e else None, E if e else 0, nthreads=NTHREADS)
+        _assert_rows(g2, r2, 2, "[782,782,%s]" % ("1" if c else "10"), rtol=1e-9)
+
+
+def test_dev_entry_point_is_asynchronous_and_reports_bad_directions():
+    """mfx_fit_batch_dev only enqueues (include/mfx.h): a non-unit fascicle direction -- the reference's per-voxel
+    ValueError (mf_utils.py:1798-1802) -- is flagged by the kernels and raised by mfx_plan_status."""
+    import torch
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    sch, dic, rng = synth.make_model("C2", N=64)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    dev = torch.device("cuda", 0)
+    V = 16
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    Y = rng.uniform(10, 100, (V, sch.shape[0]))
+    good = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2)
+    assert bool(torch.isfinite(good).all())
+    peaks[5, 3:] *= 1.01
+    with pytest.raises(ValueError, match="unit norm"):
+        engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2)
+    # the flag is cleared by the report: the next clean batch passes
+    peaks[5, 3:] /= 1.01
+    engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2)
+    # one fascicle, CSF + EAR on the device path (extras built on the device, no host round trip)
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3.0e-9)
+    sig_ear = np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * Dk) for Dk in (0.3e-9, 0.9e-9)], axis=1)
+    out = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks[:, :3].copy()).to(dev), 1, True, True,
+                               torch.from_numpy(sig_csf).to(dev), torch.from_numpy(np.ascontiguousarray(sig_ear)).to(dev), 2)
+    host = engine.fit_batch(plan, Y, np.ones(V, int), np.ones(V, bool), np.ones(V, bool), peaks[:, :3], 1, True, True,
+                            sig_csf, sig_ear, 2)
+    assert np.array_equal(out.cpu().numpy(), host)
