@@ -384,7 +384,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
   const int nappend = s_cnt[0], nfam_app = s_cnt[1];
   const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
-  const bool exhaustive = nappend > a.maxc || nfam_app > MFX_XFAM;   // workgroup-uniform
+  // (a voxel in which no support scores above zero keeps the reference's initial state: nothing to evaluate)
+  const bool nothing = !(gmax_run > 0.0);
+  const bool exhaustive = !nothing && (a.maxc == 0 || nappend > a.maxc || nfam_app > MFX_XFAM);   // workgroup-uniform
   __syncthreads();
   // scratch inside the (now idle) B buffers
   static_assert(NBUF * MP * 16 >= 8 * NW + 16 + MP, "B buffers too small for the exact-stage scratch");
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       const long pr = q / ntup;
       consider((int)(pr / N), (int)(pr % N), t);
     }
-  } else {
+  } else if (!nothing) {
     // short-listed pairs, every extra tuple (they tie when the extra column is inactive)
     for (int q = tid; q < ncand * ntup; q += WG) {
       const int c = q / ntup, t = q - c * ntup;

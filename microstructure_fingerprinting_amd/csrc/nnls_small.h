@@ -145,6 +145,15 @@ __device__ inline void nnls_gram_subsets(int n, const double* g, const double* y
   for (int mask = 1; mask < (1 << n); ++mask) {
     int idx[4], c = 0;
     for (int k = 0; k < n; ++k) if (mask & (1 << k)) idx[c++] = k;
+    // eliminate in an order that does not depend on where a column sits in the tuple (largest A'y first, as the
+    // Lawson-Hanson iteration admits them): two tuples holding the SAME columns in swapped positions (identical peak
+    // directions) then get bit-identical weights and residuals, an exact tie as in the reference, and its first hit wins
+    for (int p = 1; p < c; ++p) {
+      const int v = idx[p];
+      int q = p - 1;
+      while (q >= 0 && (y[idx[q]] < y[v] || (y[idx[q]] == y[v] && G(idx[q], idx[q]) > G(v, v)))) { idx[q + 1] = idx[q]; --q; }
+      idx[q + 1] = v;
+    }
     double A[4][5];
     for (int p = 0; p < c; ++p) { for (int q = 0; q < c; ++q) A[p][q] = G(idx[p], idx[q]); A[p][4] = y[idx[p]]; }
     bool ok = true;

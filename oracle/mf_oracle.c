@@ -260,109 +260,210 @@ static int solve3(const double* A, long lda, int M, long N1, long N2, long N3, c
 }
 
 /* ------------------------------------------------------------------------- */
-/* Lawson-Hanson NNLS ("Solving Least Squares Problems", 1974/1995, ch. 23), the
- * published algorithm behind scipy.optimize.nnls (SciPy 1.15.3, Cython port,
- * called at mfu:640).  Third-party arithmetic: the reference has no test that
- * reaches _4up, so this function is pinned only by the goldens generated with
- * SciPy 1.15.3 in the build container (tests/golden/solver_cases.npz k4_*, k5_*).
- * Small n (<= 16): unconstrained sub-problems solved by Householder QR on the
- * passive columns.                                                            */
+/* Lawson-Hanson NNLS: the algorithm behind scipy.optimize.nnls (call site mfu:640).  Third-party dependency of the
+ * reference, unpinned there (requirements.txt); this container has SciPy 1.15.3, whose `_cython_nnls._nnls` is a
+ * port of the authors' published FORTRAN 77 routine NNLS (Lawson & Hanson, "Solving Least Squares Problems", 1974,
+ * SIAM 1995, appendix C; netlib lawson-hanson/all) with its helpers H12 (Householder), G1/G2 (Givens).  This is a
+ * restatement of that published routine, statement for statement where the arithmetic is concerned: the candidate
+ * column is tested for sufficient independence (`unorm + |a|*0.01 > unorm`) and for a positive trial coefficient
+ * before it enters the passive set (that is what keeps duplicate columns and zero-residual problems from cycling),
+ * `itmax = 3 n` counts the inner loop, and rnorm is the norm of the TRANSFORMED right-hand side below the passive
+ * block - not an explicit ||A x - b||.  Pinned by tests/golden/nnls_cases.npz (SciPy 1.15.3 outputs on random,
+ * duplicate-column, zero-residual and all-negative problems, generated by tests/golden/gen_golden.py --only nnls)
+ * and by solver_cases.npz k4_*, k5_*.  Where a sum's order is BLAS-internal in SciPy the results agree to rounding
+ * (1e-12), not bit for bit: the reference's own pick among rounding-level ties of _4up is not reproducible either.  */
 #define NNLS_MAXN 16
-static void ls_passive(const double* As, int M, int n, const int* P, int np_, const double* b, double* s, double* work) {
-  /* solve min || As[:,P] z - b ||, z -> s[P], others 0.  work: M*(np_+1) doubles */
-  double* Q = work; /* column-major M x (np_+1): columns then rhs */
-  for (int c = 0; c < np_; c++)
-    for (int i = 0; i < M; i++) Q[c * M + i] = As[i * n + P[c]];
-  for (int i = 0; i < M; i++) Q[np_ * M + i] = b[i];
-  double diag[NNLS_MAXN];
-  for (int c = 0; c < np_; c++) {
-    double nrm = 0;
-    for (int i = c; i < M; i++) nrm += Q[c * M + i] * Q[c * M + i];
-    nrm = sqrt(nrm);
-    double alpha = (Q[c * M + c] > 0) ? -nrm : nrm;
-    double v0 = Q[c * M + c] - alpha;
-    double vnorm2 = v0 * v0;
-    for (int i = c + 1; i < M; i++) vnorm2 += Q[c * M + i] * Q[c * M + i];
-    diag[c] = alpha;
-    if (vnorm2 == 0) continue;
-    Q[c * M + c] = v0;
-    for (int c2 = c + 1; c2 <= np_; c2++) {
-      double dot = 0;
-      for (int i = c; i < M; i++) dot += Q[c * M + i] * Q[c2 * M + i];
-      double f = 2 * dot / vnorm2;
-      for (int i = c; i < M; i++) Q[c2 * M + i] -= f * Q[c * M + i];
+/* H12: construct (mode 1) / apply (mode 2) the Householder transformation Q = I + u u'/b; 0-based lpivot < l1 <= m.
+ * u has stride 1; c: ncv vectors, element stride ice, vector stride icv. */
+static void h12(int mode, int lpivot, int l1, int m, double* u, double* up, double* c, int ice, int icv, int ncv) {
+  if (lpivot < 0 || lpivot >= l1 || l1 > m) return;
+  double cl = fabs(u[lpivot]);
+  if (mode != 2) {
+    for (int j = l1; j < m; j++) cl = fmax(fabs(u[j]), cl);
+    if (cl <= 0) return;
+    const double clinv = 1.0 / cl;
+    double sm = (u[lpivot] * clinv) * (u[lpivot] * clinv);
+    for (int j = l1; j < m; j++) sm += (u[j] * clinv) * (u[j] * clinv);
+    cl = cl * sqrt(sm);
+    if (u[lpivot] > 0) cl = -cl;
+    *up = u[lpivot] - cl;
+    u[lpivot] = cl;
+  } else if (cl <= 0) {
+    return;
+  }
+  if (ncv <= 0) return;
+  double bb = (*up) * u[lpivot];
+  if (bb >= 0) return;
+  bb = 1.0 / bb;
+  for (int j = 0; j < ncv; j++) {
+    double* cj = c + (long)j * icv;
+    double sm = cj[(long)lpivot * ice] * (*up);
+    for (int i = l1; i < m; i++) sm += cj[(long)i * ice] * u[i];
+    if (sm != 0) {
+      sm *= bb;
+      cj[(long)lpivot * ice] += sm * (*up);
+      for (int i = l1; i < m; i++) cj[(long)i * ice] += sm * u[i];
     }
   }
-  double z[NNLS_MAXN];
-  for (int c = np_ - 1; c >= 0; c--) {
-    double t = Q[np_ * M + c];
-    for (int c2 = c + 1; c2 < np_; c2++) t -= Q[c2 * M + c] * z[c2];
-    z[c] = t / diag[c];
+}
+static void g1(double a, double b, double* cterm, double* sterm, double* sig) {
+  if (fabs(a) > fabs(b)) {
+    const double xr = b / a, yr = sqrt(1.0 + xr * xr);
+    *cterm = copysign(1.0 / yr, a);
+    *sterm = (*cterm) * xr;
+    *sig = fabs(a) * yr;
+  } else if (b != 0) {
+    const double xr = a / b, yr = sqrt(1.0 + xr * xr);
+    *sterm = copysign(1.0 / yr, b);
+    *cterm = (*sterm) * xr;
+    *sig = fabs(b) * yr;
+  } else {
+    *sig = 0; *cterm = 0; *sterm = 1;
   }
-  for (int i = 0; i < n; i++) s[i] = 0;
-  for (int c = 0; c < np_; c++) s[P[c]] = z[c];
 }
 
-static int nnls_lh(const double* As /* M x n row-major */, int M, int n, const double* b, double* x, double* rnorm,
+static int nnls_lh(const double* As /* M x n row-major */, int M, int n, const double* b_in, double* x, double* rnorm,
                    double* work /* M*(n+2) */) {
-  int inP[NNLS_MAXN] = {0};
-  double w[NNLS_MAXN], s[NNLS_MAXN];
-  double* resid = work + (size_t)M * (n + 1);
-  const int maxiter = 3 * n;
-  int iter = 0;
-  for (int i = 0; i < n; i++) x[i] = 0;
-  /* tolerance as in SciPy's implementation: 10 * max(m, n) * spacing(1) */
-  const double tol = 10.0 * (M > n ? M : n) * 2.220446049250313e-16;
-  for (int i = 0; i < M; i++) resid[i] = b[i];
-  for (;;) {
-    for (int j = 0; j < n; j++) {
-      double t = 0;
-      for (int i = 0; i < M; i++) t += As[i * n + j] * resid[i];
-      w[j] = t;
+  const int m = M;
+  double* A = work;                       /* column-major m x n working copy */
+  double* b = work + (size_t)m * n;       /* transformed right-hand side */
+  double* zz = b + m;
+  double w[NNLS_MAXN];
+  int index[NNLS_MAXN];
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < m; i++) A[(size_t)j * m + i] = As[(size_t)i * n + j];
+  for (int i = 0; i < m; i++) b[i] = b_in[i];
+  const double factor = 0.01;
+  const int itmax = 3 * n;
+  int iter = 0, mode = 1;
+  for (int i = 0; i < n; i++) { x[i] = 0; index[i] = i; w[i] = 0; }
+  int iz2 = n - 1, iz1 = 0, nsetp = 0, npp1 = 0;   /* npp1: 0-based row of the next pivot */
+  double up = 0;
+  for (;;) {   /* main loop */
+    if (iz1 > iz2 || nsetp >= m) break;
+    for (int iz = iz1; iz <= iz2; iz++) {   /* dual (negative gradient) vector on set Z */
+      const int j = index[iz];
+      double sm = 0;
+      for (int l = npp1; l < m; l++) sm += A[(size_t)j * m + l] * b[l];
+      w[j] = sm;
     }
-    int jbest = -1;
-    double wbest = tol;
-    for (int j = 0; j < n; j++)
-      if (!inP[j] && w[j] > wbest) { wbest = w[j]; jbest = j; }
-    if (jbest < 0) break;
-    inP[jbest] = 1;
+    int j = -1, iz = -1, accepted = 0;
     for (;;) {
-      int P[NNLS_MAXN], np_ = 0;
-      for (int j = 0; j < n; j++) if (inP[j]) P[np_++] = j;
-      ls_passive(As, M, n, P, np_, b, s, work);
-      int allpos = 1;
-      for (int c = 0; c < np_; c++) if (s[P[c]] <= 0) allpos = 0;
-      if (allpos) break;
-      if (++iter > maxiter) return ORC_ERR_NNLS_ITER;
-      double alpha = INFINITY;
-      for (int c = 0; c < np_; c++) {
-        int j = P[c];
-        if (s[j] <= 0) {
-          double a = x[j] / (x[j] - s[j]);
-          if (a < alpha) alpha = a;
+      double wmax = 0;
+      int izmax = -1;
+      for (int q = iz1; q <= iz2; q++) {
+        const int jq = index[q];
+        if (w[jq] > wmax) { wmax = w[jq]; izmax = q; }
+      }
+      if (wmax <= 0) break;   /* Kuhn-Tucker conditions hold */
+      iz = izmax;
+      j = index[iz];
+      double* Aj = A + (size_t)j * m;
+      const double asave = Aj[npp1];
+      h12(1, npp1, npp1 + 1, m, Aj, &up, NULL, 1, 1, 0);
+      double unorm = 0;
+      for (int l = 0; l < nsetp; l++) unorm += Aj[l] * Aj[l];
+      unorm = sqrt(unorm);
+      volatile double t1 = unorm + fabs(Aj[npp1]) * factor;   /* DIFF(): the comparison must not be optimised away */
+      if (t1 - unorm > 0) {
+        for (int l = 0; l < m; l++) zz[l] = b[l];
+        h12(2, npp1, npp1 + 1, m, Aj, &up, zz, 1, 1, 1);
+        const double ztest = zz[npp1] / Aj[npp1];
+        if (ztest > 0) { accepted = 1; break; }
+      }
+      Aj[npp1] = asave;   /* reject j as a candidate */
+      w[j] = 0;
+    }
+    if (!accepted) break;
+    /* move j from set Z to set P */
+    for (int l = 0; l < m; l++) b[l] = zz[l];
+    index[iz] = index[iz1];
+    index[iz1] = j;
+    iz1++;
+    nsetp = npp1 + 1;
+    npp1++;
+    {
+      double* Aj = A + (size_t)j * m;
+      for (int jz = iz1; jz <= iz2; jz++) {
+        const int jj = index[jz];
+        h12(2, nsetp - 1, npp1, m, Aj, &up, A + (size_t)jj * m, 1, m, 1);
+      }
+      if (nsetp != m) for (int l = npp1; l < m; l++) Aj[l] = 0;
+    }
+    w[j] = 0;
+#define NNLS_SOLVE_TRI()                                                              \
+    do {                                                                              \
+      int jj_ = 0;                                                                    \
+      for (int l = 0; l < nsetp; l++) {                                               \
+        const int ip = nsetp - 1 - l;                                                 \
+        if (l != 0) for (int ii = 0; ii <= ip; ii++) zz[ii] -= A[(size_t)jj_ * m + ii] * zz[ip + 1]; \
+        jj_ = index[ip];                                                              \
+        zz[ip] /= A[(size_t)jj_ * m + ip];                                            \
+      }                                                                               \
+    } while (0)
+    NNLS_SOLVE_TRI();
+    int fail = 0;
+    for (;;) {   /* secondary loop */
+      if (++iter > itmax) { mode = 3; fail = 1; break; }
+      double alpha = 2.0;
+      int jj = -1;
+      for (int ip = 0; ip < nsetp; ip++) {
+        const int l = index[ip];
+        if (zz[ip] <= 0) {
+          const double t = -x[l] / (zz[ip] - x[l]);
+          if (alpha > t) { alpha = t; jj = ip; }
         }
       }
-      for (int j = 0; j < n; j++) x[j] = x[j] + alpha * (s[j] - x[j]);
-      for (int j = 0; j < n; j++) if (inP[j] && x[j] <= tol) { inP[j] = 0; x[j] = 0; }
-      int any = 0;
-      for (int j = 0; j < n; j++) any |= inP[j];
-      if (!any) break;
+      if (alpha == 2.0) break;   /* all trial coefficients feasible */
+      for (int ip = 0; ip < nsetp; ip++) {
+        const int l = index[ip];
+        x[l] += alpha * (zz[ip] - x[l]);
+      }
+      int i = index[jj];
+      for (;;) {   /* move coefficient i from set P to set Z */
+        x[i] = 0;
+        if (jj != nsetp - 1) {
+          for (int jq = jj + 1; jq < nsetp; jq++) {
+            const int ii = index[jq];
+            index[jq - 1] = ii;
+            double cc, ss, sig;
+            g1(A[(size_t)ii * m + jq - 1], A[(size_t)ii * m + jq], &cc, &ss, &sig);
+            A[(size_t)ii * m + jq - 1] = sig;
+            A[(size_t)ii * m + jq] = 0;
+            for (int l = 0; l < n; l++) {
+              if (l != ii) {
+                const double t = A[(size_t)l * m + jq - 1];
+                A[(size_t)l * m + jq - 1] = cc * t + ss * A[(size_t)l * m + jq];
+                A[(size_t)l * m + jq] = -ss * t + cc * A[(size_t)l * m + jq];
+              }
+            }
+            const double t = b[jq - 1];
+            b[jq - 1] = cc * t + ss * b[jq];
+            b[jq] = -ss * t + cc * b[jq];
+          }
+        }
+        npp1 = nsetp - 1;
+        nsetp--;
+        iz1--;
+        index[iz1] = i;
+        /* the remaining coefficients in set P should be feasible; any that are not (round-off) go to set Z too */
+        int again = 0;
+        for (int q = 0; q < nsetp; q++) {
+          i = index[q];
+          if (x[i] <= 0) { jj = q; again = 1; break; }
+        }
+        if (!again) break;
+      }
+      for (int l = 0; l < m; l++) zz[l] = b[l];
+      NNLS_SOLVE_TRI();
     }
-    for (int j = 0; j < n; j++) x[j] = s[j];
-    for (int i = 0; i < M; i++) {
-      double t = b[i];
-      for (int j = 0; j < n; j++) t -= As[i * n + j] * x[j];
-      resid[i] = t;
-    }
+    if (fail) break;
+    for (int ip = 0; ip < nsetp; ip++) x[index[ip]] = zz[ip];
   }
-  double r2 = 0;
-  for (int i = 0; i < M; i++) {
-    double t = b[i];
-    for (int j = 0; j < n; j++) t -= As[i * n + j] * x[j];
-    r2 += t * t;
-  }
-  *rnorm = sqrt(r2);
-  return ORC_OK;
+  double sm = 0;
+  if (npp1 < m) for (int i = npp1; i < m; i++) sm += b[i] * b[i];
+  *rnorm = sqrt(sm);
+  return mode == 3 ? ORC_ERR_NNLS_ITER : ORC_OK;
 }
 
 /* solve_exhaustive_posweights_4up: mfu:612-657 (itertools.product order = last index fastest) */
@@ -402,6 +503,16 @@ static int solve4up(const double* A, long lda, int M, const long* sizes, int Kp,
   for (int k = 0; k < Kp; k++) { w_out[k] = wb[k]; sub[k] = sb[k]; }
   *min_obj_out = min_obj;
   free(As); free(work);
+  return rc;
+}
+
+/* scipy.optimize.nnls(A, b) on its own (A row-major M x n, n <= 16): the unit the goldens of nnls_cases.npz pin */
+int orc_nnls(const double* A, int M, int n, const double* b, double* x, double* rnorm) {
+  if (n > NNLS_MAXN || n < 1 || M < 1) return ORC_ERR_ARG;
+  double* work = (double*)malloc(sizeof(double) * (size_t)M * (n + 2));
+  if (!work) return ORC_ERR_ARG;
+  const int rc = nnls_lh(A, M, n, b, x, rnorm, work);
+  free(work);
   return rc;
 }
 

@@ -56,6 +56,8 @@ def lib():
                                                  C.c_int]
         _LIB.orc_monte_carlo_average.restype = C.c_int
         _LIB.orc_max_threads.restype = C.c_int
+        _LIB.orc_nnls.argtypes = [dp, C.c_int, C.c_int, dp, dp, dp]
+        _LIB.orc_nnls.restype = C.c_int
     return _LIB
 
 
@@ -280,6 +282,20 @@ def monte_carlo_average(sim_phases, delta_mapping, gscaling, Dscaling, num_spins
     if rc:
         raise IndexError("delta_mapping points outside the phase table")
     return out
+
+
+def nnls(A, b):
+    """scipy.optimize.nnls(A, b) restated (mfu:640): returns (x, rnorm); RuntimeError like SciPy when 3n iterations do not suffice."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(A.shape[1])
+    rn = np.zeros(1)
+    rc = lib().orc_nnls(_dp(A), A.shape[0], A.shape[1], _dp(b), _dp(x), _dp(rn))
+    if rc == 3:
+        raise RuntimeError("Maximum number of iterations reached.")
+    if rc:
+        raise RuntimeError("oracle nnls error %d" % rc)
+    return x, float(rn[0])
 
 
 def max_threads():

@@ -503,6 +503,37 @@ def gen_mc(mfu):
     print("mc_cases.npz written", out["sig_direct"][:4], out["sig_files_bdouble"][:4])
 
 
+def gen_nnls():
+    """scipy.optimize.nnls (the third-party solver under solve_exhaustive_posweights_4up, mf_utils.py:640) on seeded
+    4- to 6-column problems, incl. the degenerate ones that make a naive Lawson-Hanson loop cycle: duplicate columns,
+    dependent columns, zero residual, nothing to fit.  Outputs of SciPy as installed in the build container."""
+    import scipy
+    import scipy.optimize as so
+    rng = np.random.default_rng(77)
+    M = 40
+    t = np.linspace(0, 3, M)
+    out = {"scipy_version": np.array(scipy.__version__)}
+    k = 0
+    for it in range(160):
+        n = int(rng.integers(4, 7))
+        kind = it % 8
+        A = rng.uniform(0.05, 1, (M, n)) * np.exp(-np.outer(t, rng.uniform(0, 2, n)))
+        xt = rng.uniform(0, 300, n) * (rng.uniform(size=n) < 0.6)
+        b = A @ xt + rng.normal(0, 10, M)
+        if kind == 1: A[:, 1] = A[:, 0]
+        if kind == 2: b = A @ xt
+        if kind == 3: b = -np.abs(b)
+        if kind == 4: A[:, 2] = 0.5 * A[:, 0] + 0.5 * A[:, 1]
+        if kind == 5: A[:, 1] = A[:, 0] * (1 + 1e-9)
+        if kind == 6: A[:, 1] = A[:, 0]; b = 100 * A[:, 0]
+        x, rn = so.nnls(A, b)
+        out["A_%d" % k], out["b_%d" % k], out["x_%d" % k], out["rn_%d" % k], out["kind_%d" % k] = A, b, x, np.float64(rn), np.int64(kind)
+        k += 1
+    out["count"] = np.int64(k)
+    np.savez_compressed(os.path.join(OUT, "nnls_cases.npz"), **out)
+    print("nnls_cases.npz written (%d problems)" % k)
+
+
 def gen_real(mfu, mfmod, part=None):
     """The real dictionaries held by the reference's own tests, stored as DATA (arrays only), plus a few voxels fitted
     by the reference itself at full dictionary size:
@@ -575,7 +606,7 @@ if __name__ == "__main__":
     todo = {"solver": lambda: gen_solver(mfu), "rotation": lambda: gen_rotation(mfu),
             "fit": lambda: gen_fit(mfu, mfmod), "c2": lambda: gen_c2_small(mfu, mfmod),
             "inputs": lambda: gen_inputs(mfu, mfmod), "cleanup": lambda: gen_cleanup(mfu, mfmod),
-            "mc": lambda: gen_mc(mfu), "real": lambda: gen_real(mfu, mfmod, a.part)}
+            "mc": lambda: gen_mc(mfu), "real": lambda: gen_real(mfu, mfmod, a.part), "nnls": gen_nnls}
     for k, fn in todo.items():
         if a.only in (None, k):
             fn()

@@ -623,6 +623,14 @@ def test_k2_with_compartments_vs_oracle(c, e, N, V):
     got = engine.fit_batch(ms.plan_for(sch), Y, Kv, cm, em, peaks, 2, bool(c), bool(e),
                            sig_csf if c else None, sig_ear if e else None, E if e else 0)
     ids = [3, 4] + ([5 + c + 1] if e else [])
+    if c and e:
+        # _4up: the reference's residual comes out of scipy.optimize.nnls (norm of a Householder-transformed vector,
+        # BLAS dnrm2): tuples that differ only in the atom of an INACTIVE compartment tie up to its rounding, so the
+        # index of a compartment with zero weight is not reproducible (and is multiplied by zero in every map)
+        got, ref = got.copy(), ref.copy()
+        for col_nu, col_id in ((1, 3), (2, 4), (6, 7)):
+            off = ref[:, col_nu] <= 1e-9
+            got[off, col_id] = 0; ref[off, col_id] = 0
     assert np.array_equal(got[:, ids], ref[:, ids])
     tol = 1e-9 if not (c and e) else 1e-7     # _4up: third-party NNLS in the reference, Gram-based optimum here
     assert np.allclose(got, ref, rtol=tol, atol=1e-9)

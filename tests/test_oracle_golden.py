@@ -194,3 +194,19 @@ def test_fit_goldens_k1_and_c2():
     maps = _params_to_maps(P, 2, 0, 0, {"rad": c["rad"], "fin": c["fin"]}, None)
     for name, arr in maps.items():
         assert np.allclose(arr, c["map_" + name].reshape(-1), rtol=1e-9, atol=1e-12), name
+
+
+def test_nnls_restatement_vs_scipy_goldens():
+    """The oracle's Lawson-Hanson routine against SciPy's own outputs (tests/golden/nnls_cases.npz), incl. problems
+    with duplicate / dependent columns, zero residual and nothing to fit, where a plain active-set loop cycles (the
+    published routine rejects such candidates).  Exact ties (two identical columns: kinds 1, 6) may put the weight on
+    either twin - SciPy's own choice depends on its BLAS - so there the twins' weights are compared as a sum."""
+    d = np.load(os.path.join(G, "nnls_cases.npz"))
+    for k in range(int(d["count"])):
+        A, b, xs, rs, kind = d["A_%d" % k], d["b_%d" % k], d["x_%d" % k], float(d["rn_%d" % k]), int(d["kind_%d" % k])
+        x, rn = orc.nnls(A, b)
+        assert abs(rn - rs) <= 1e-9 * max(1.0, rs), (k, kind, rn, rs)
+        if kind in (1, 6):
+            x, xs = x.copy(), xs.copy()
+            x[0] += x[1]; x[1] = 0.0; xs[0] += xs[1]; xs[1] = 0.0
+        assert np.allclose(x, xs, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(xs).max())), (k, kind, x, xs)

@@ -47,8 +47,21 @@ def _second_peak(rng, p1, deg):
     return p2 / np.linalg.norm(p2, axis=1, keepdims=True)
 
 
-def _assert_rows(got, ref, maxfasc, what, rtol=1e-5):
+def _assert_rows(got, ref, maxfasc, what, rtol=1e-5, ids_where_active=False, ear=None):
+    """ids_where_active: compare an atom index only where the oracle gives its compartment a positive weight.  Used for
+    the _4up class only: there the reference's residual is the norm of a Householder-transformed vector inside
+    scipy.optimize.nnls, whose last bits (and with them the winner among EXACTLY tied tuples - all of them when a
+    compartment is inactive) depend on SciPy's BLAS (dnrm2, dlarfgp: tests/golden/nnls_cases.npz pins the solver to
+    rounding, not bit for bit); the index of an inactive compartment is multiplied by zero in every map the reference
+    produces (mf.py:1111-1117, 1148).  ear = (column of nu_ear, column of the EAR index)."""
     ids = slice(1 + maxfasc, 1 + 2 * maxfasc)
+    if ids_where_active:
+        got, ref = got.copy(), ref.copy()
+        off = ref[:, 1:1 + maxfasc] <= 1e-9   # (Lawson-Hanson leaves ~1e-14 on atoms it could have dropped)
+        got[:, ids][off] = 0; ref[:, ids][off] = 0
+        if ear is not None:
+            off = ref[:, ear[0]] <= 1e-9
+            got[off, ear[1]] = 0; ref[off, ear[1]] = 0
     bad = np.where(np.any(got[:, ids] != ref[:, ids], axis=1))[0]
     assert bad.size == 0, "%s: atom indices differ from the oracle in voxels %s (got %s, oracle %s)" % (
         what, bad[:8], got[bad[:3], ids], ref[bad[:3], ids])
@@ -168,8 +181,9 @@ def test_ukbb_real_dictionary_through_mfmodel_vs_oracle():
                         nthreads=NTHREADS)
     _assert_rows(got[:nK2], ref[:nK2], 2, "UKBB K=2")
     _assert_rows(got[nK2:nK2 + nC], ref[nK2:nK2 + nC], 2, "UKBB K=2+CSF")
-    _assert_rows(got[nK2 + nC:], ref[nK2 + nC:], 2, "UKBB K=2+CSF+EAR")
-    assert np.array_equal(got[:, 7], ref[:, 7])   # EAR atom
+    _assert_rows(got[nK2 + nC:], ref[nK2 + nC:], 2, "UKBB K=2+CSF+EAR", ids_where_active=True, ear=(6, 7))
+    act = ref[:, 6] > 1e-9
+    assert np.array_equal(got[act, 7], ref[act, 7])   # EAR atom
     # voxels fitted by the reference itself
     for name in ("k2", "k2csf", "k2csfear"):
         fn = os.path.join(G, "real_ukbb_fit_%s.npz" % name)
@@ -270,7 +284,8 @@ def test_k2x_flood_voxels_vs_oracle(c, e):
     nfb = L.lib().mfx_debug_last_fallback_count()
     ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one * c, one * e, peaks, 2, bool(c), bool(e),
                         sig_csf if c else None, sig_ear if e else None, E if e else 0, nthreads=NTHREADS)
-    _assert_rows(got, ref, 2, "flood voxels csf=%d ear=%d" % (c, e), rtol=1e-5 if (c and e) else 1e-9)
+    _assert_rows(got, ref, 2, "flood voxels csf=%d ear=%d" % (c, e), rtol=1e-5 if (c and e) else 1e-9,
+                 ids_where_active=bool(c and e), ear=(6, 7) if (c and e) else None)
     assert nfb <= n_all_tie, "exhaustive pass taken by %d voxels" % nfb
 
 
@@ -292,7 +307,7 @@ def test_k2x_exhaustive_last_resort():
     finally:
         lib.mfx_debug_set_k2x_maxc(-1)
     ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=NTHREADS)
-    _assert_rows(got, ref, 2, "exhaustive pass")
+    _assert_rows(got, ref, 2, "exhaustive pass", ids_where_active=True, ear=(6, 7))
     assert nfb == V
 
 
@@ -312,8 +327,9 @@ def test_c4_full_size_vs_oracle():
     got = engine.fit_batch(plan, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E)
     nfb = L.lib().mfx_debug_last_fallback_count()
     ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one, one, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=NTHREADS)
-    _assert_rows(got, ref, 2, "config 4")
-    assert np.array_equal(got[:, 7], ref[:, 7]), "EAR atom differs"
+    _assert_rows(got, ref, 2, "config 4", ids_where_active=True, ear=(6, 7))
+    act = ref[:, 6] > 1e-9
+    assert np.array_equal(got[act, 7], ref[act, 7]), "EAR atom differs"
     assert nfb <= n_all_tie
     for c, e in ((1, 0), (0, 1)):
         pk2, Y2, _ = _flood_voxels(rng, plan, N, E, sig_csf * c, sig_ear * e, V)
