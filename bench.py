@@ -3,19 +3,23 @@
 
 Workload (BASELINE.json configs[1], "C2"): 1e5 voxels, 2 fascicles, 782-atom x 200-measurement
 multishell dictionary, exhaustive 2-sub-dictionary NNLS.  One "step" = one pass of the hot path
-(rotation + exhaustive NNLS + parameter packing) over the whole 1e5-voxel batch, inputs already
-resident in HBM.  With N GPUs every rank processes its own 1e5-voxel shard (weak scaling, no
-data-path collective); rank 0 builds the dictionary tables and broadcasts them once over RCCL.
+(rotation + exhaustive NNLS + parameter packing) over the whole batch, inputs already resident in HBM.
+With N GPUs: --scaling weak (default) gives every rank its own 1e5-voxel shard, --scaling strong splits
+ONE 1e5-voxel ROI over the ranks (BASELINE config 3 as worded); no data-path collective either way, rank 0
+builds the dictionary tables and broadcasts them once over RCCL.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries, measured in the same process over a few
+steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4 and 1 (`c4`, `c1`), the
+PCIe-inclusive rate of the host entry point (`host_api`) and the CPU baseline on all host cores.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -27,13 +31,19 @@ sys.path.insert(0, ROOT)
 FLOP_PER_VOXEL = 261.0e6      # 244.6 MFLOP Gram + 16.4 MFLOP vector work (the reference's FP64 count)
 BYTES_PER_VOXEL = 1710.0      # y (1600 B) + peaks (48 B) + flags in, 56 B out
 PEAK_FP64_MFMA_TFLOPS = 78.6  # AMD public spec, FP64 matrix (the CDNA4 guide lists no FP64 MFMA rate)
+PEAK_FP64_VALU_TFLOPS = 78.6  # FP64 vector FMA (measured ~62: tools/micro/f64_rates.hip)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense FP16/BF16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
 # The dominant kernel (mfx_fit_k2s_kernel) ranks the atom pairs with a Gram computed from operands split in two
 # FP16 halves: 3 MFMA products per 32x32x16 block over the padded problem (800 x 800 atoms x 208 rows).
 EXEC_F16_FLOP_PER_VOXEL = 3 * 2.0 * 800 * 800 * 208
 # FP32 screening table bytes a voxel pulls from L2: 6 passes over a rotated dictionary (200 rows x 782 atoms x 8 B) + the
 # shared last tile's operand read by all 8 waves
 L2_TABLE_BYTES_PER_VOXEL = 6 * 200 * 782 * 8.0 + 8 * 32 * 200 * 8.0
+# config 4, sub-dictionaries [782, 782, 1, E]: the C2 Gram + 782^2 E four-column NNLS of ~150 flops
+C4_E = 10
+FLOP_PER_VOXEL_C4 = 244.6e6 + 782.0 * 782.0 * C4_E * 150.0
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_k2s.json")
 
 
 def parse():
@@ -41,10 +51,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--voxels", type=int, default=100000, help="voxels per GPU (default: BASELINE config 2)")
+    ap.add_argument("--voxels", type=int, default=100000, help="voxels per GPU (weak) or in total (strong); default: BASELINE config 2")
     ap.add_argument("--atoms", type=int, default=782)
-    ap.add_argument("--cpu-sample", type=int, default=768, help="voxels timed on the host cores for cpu_baseline")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="voxels timed on the host cores (0: ~40 per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp64_kernel / c4 / c1 / host_api measurements")
     return ap.parse_args()
 
 
@@ -57,12 +69,54 @@ def build_model(atoms):
     return sch, dic, ms
 
 
+def synth_voxels(plan, V, N, M, dev, seed, K=2, extra_cols=None, snr=30.0):
+    """Synthetic voxels generated on the device with the library's own rotation kernel (SURVEY.md section 8d recipe):
+    y = 500 sum_k nu_k D_k[:, a_k] (+ nu_x x) + N(0, 500/snr)."""
+    import torch
+    from microstructure_fingerprinting_amd import engine, synth
+    rng = np.random.default_rng(seed)
+    peaks_h = np.concatenate([synth.unit_vectors(rng, V) for _ in range(K)], axis=1)
+    atoms_h = rng.integers(0, N, (V, K)).astype(np.int32)
+    ncomp = K + (extra_cols.shape[1] if extra_cols is not None else 0)
+    nu_h = rng.dirichlet(np.ones(ncomp), V)
+    d_peaks = torch.from_numpy(peaks_h).to(dev)
+    d_Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
+    for k in range(K):
+        col = engine.rotate_columns_dev(plan, d_peaks[:, 3 * k:3 * k + 3].contiguous(),
+                                        torch.from_numpy(atoms_h[:, k].copy()).to(dev))      # [V, M]
+        d_Y += 500.0 * torch.from_numpy(nu_h[:, k:k + 1].copy()).to(dev) * col
+    if extra_cols is not None:
+        d_Y += 500.0 * torch.from_numpy(nu_h[:, K:].copy()).to(dev) @ torch.from_numpy(np.ascontiguousarray(extra_cols.T)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + seed)
+    d_Y += torch.randn((V, M), dtype=torch.float64, device=dev, generator=gen) * (500.0 / snr)
+    return peaks_h, d_peaks, d_Y
+
+
+def timed(step, steps, warmup, dev, lib):
+    """(seconds per step by the wall clock, ms of the dominant kernel by HIP events on the launch stream)."""
+    import torch
+    for _ in range(warmup):
+        step()
+    lib.mfx_set_profiling(1)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        step()
+        kms.append(lib.mfx_last_kernel_ms())
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    lib.mfx_set_profiling(0)
+    return dt, (float(np.mean(kms)) if kms and min(kms) > 0 else None)
+
+
 def main():
     a = parse()
     import torch
     import torch.distributed as dist
     from microstructure_fingerprinting_amd import _lib as L
-    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import engine
     from microstructure_fingerprinting_amd import mf_utils as mfu
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,21 +145,15 @@ def main():
     plan = engine.Plan(ms.device_tables(), scheme=sch)
     M, N = sch.shape[0], ms.num_subs
 
-    # ---- synthetic voxels, generated on the device with the library's own rotation kernel
-    V = a.voxels
-    rng = np.random.default_rng(1000 + rank)
-    peaks_h = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
-    atoms_h = rng.integers(0, N, (V, 2)).astype(np.int32)
-    nu_h = rng.dirichlet(np.ones(2), V)
-    d_peaks = torch.from_numpy(peaks_h).to(dev)
-    d_Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
-    for k in range(2):
-        col = engine.rotate_columns_dev(plan, d_peaks[:, 3 * k:3 * k + 3].contiguous(),
-                                        torch.from_numpy(atoms_h[:, k].copy()).to(dev))      # [V, M]
-        d_Y += 500.0 * torch.from_numpy(nu_h[:, k:k + 1].copy()).to(dev) * col
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    d_Y += torch.randn((V, M), dtype=torch.float64, device=dev, generator=gen) * (500.0 / 30.0)
+    # ---- this rank's voxels: its own shard (weak) or its contiguous block of ONE global ROI (strong; the global ROI is
+    # generated from per-block seeds, so that the set of voxels does not depend on how it is split only in its totals)
+    if a.scaling == "strong" and world > 1:
+        from microstructure_fingerprinting_amd import dist as mdist
+        lo, hi = mdist.shard_range(a.voxels, rank, world)
+        V, global_V = hi - lo, a.voxels
+    else:
+        V, global_V = a.voxels, world * a.voxels
+    peaks_h, d_peaks, d_Y = synth_voxels(plan, V, N, M, dev, 1000 + rank)
     d_out = torch.zeros((V, 7), dtype=torch.float64, device=dev)
     lib = L.lib()
     stream = torch.cuda.current_stream(dev)
@@ -133,13 +181,15 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     lib.mfx_set_profiling(0)
+    L.check(lib.mfx_plan_status(plan.handle(), stream.cuda_stream))
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
-    value = world * V * a.steps / elapsed
+    value = global_V * a.steps / elapsed
+    handed_back = int(lib.mfx_debug_last_fallback_count())
 
     # sanity: selected atoms are plausible indices
     ids = d_out[:, 3:5]
@@ -147,24 +197,25 @@ def main():
 
     res = None
     if rank == 0:
+        screen = os.environ.get("MFX_K2_SCREEN", "1") != "0"
         kavg = float(np.mean(kern_ms)) if kern_ms and min(kern_ms) > 0 else None
         roof = None
         if kavg:
             ach = FLOP_PER_VOXEL * V / (kavg * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if os.environ.get("MFX_K2_SCREEN", "1") == "0"
-                              else "r01_pmc_traffic_k2s.json")
+            # HBM bytes per launch from the PMC counters: NOT measured in this run (rocprofv3 --pmc needs its own passes);
+            # taken from the committed profile of the same binary and workload, and tagged as such
+            traffic, tfrom = None, None
+            tf = os.path.join(ROOT, PMC_PROFILE if screen else os.path.join("profiles", "r01_pmc_traffic.json"))
             if os.path.exists(tf) and V == 100000 and a.atoms == 782:
                 try:
-                    traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                    traffic, tfrom = json.load(open(tf)).get("hbm_bytes_per_launch"), os.path.relpath(tf, ROOT)
                 except Exception:
                     traffic = None
-            screen = os.environ.get("MFX_K2_SCREEN", "1") != "0"
             if screen:
                 # achieved: the reference's algorithmic FP64 flop count per second, priced against the dense MFMA
                 # peak of the type the dominant kernel multiplies in (FP16).  exec_*: what the matrix pipe really did.
                 roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_from": tfrom,
                         "kernel": "mfx_fit_k2s_kernel<13, false, 3>", "kernel_ms": round(kavg, 3),
                         "flop_per_voxel": FLOP_PER_VOXEL,
                         "exec_f16_mfma_tflops": round(EXEC_F16_FLOP_PER_VOXEL * V / (kavg * 1e-3) / 1e12, 1),
@@ -179,26 +230,32 @@ def main():
                         # x 8 B per pass; an XCD's L2 delivers 66-73 GB/s per CU (MI355X_MICROARCH.md), 68 x 256 here
                         "l2_table_bytes_per_voxel": L2_TABLE_BYTES_PER_VOXEL,
                         "l2_table_TBps": round(L2_TABLE_BYTES_PER_VOXEL * V / (kavg * 1e-3) / 1e12, 2),
-                        "l2_table_frac_of_17.4TBps": round(L2_TABLE_BYTES_PER_VOXEL * V / (kavg * 1e-3) / 17.4e12, 3)}
+                        "l2_table_frac_of_17.4TBps": round(L2_TABLE_BYTES_PER_VOXEL * V / (kavg * 1e-3) / 17.4e12, 3),
+                        "handed_back_to_fp64_kernel": handed_back}
             else:
                 roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_from": tfrom,
                         "kernel": "mfx_fit_k2_kernel<50,false,true,8,2,2>", "kernel_ms": round(kavg, 3),
                         "flop_per_voxel": FLOP_PER_VOXEL, "hbm_bytes_per_voxel_algorithmic": BYTES_PER_VOXEL,
                         "achieved_hbm_GBps_algorithmic": round(BYTES_PER_VOXEL * V / (kavg * 1e-3) / 1e9, 3)}
+        extras = {}
+        if world == 1 and not a.no_extras:
+            extras = extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev, lib, screen)
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baseline(sch, ms, d_Y, peaks_h, d_out, min(a.cpu_sample, V))
+            cpu = cpu_baseline(sch, ms, d_Y, peaks_h, d_out, V, a.cpu_sample)
         res = {"metric": "voxels/sec, 2-fascicle exhaustive NNLS, 782-atom x 200-measurement dictionary",
                "value": round(value, 1), "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(ms_per_step, 3), "ms_per_voxel": round(ms_per_step / V, 6),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f64" if os.environ.get("MFX_K2_SCREEN", "1") == "0" else "f64 (pairs ranked on split-f16 MFMA, short list re-evaluated in f64)",
+               "ms_per_step": round(ms_per_step, 3), "ms_per_voxel": round(ms_per_step / max(global_V // world, 1), 6),
+               "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None,
+               "dtype": "f64" if not screen else "f64 (pairs ranked on split-f16 MFMA, short list re-evaluated in f64)",
                "data": "synthetic",
-               "config": {"workload": "C2: %d voxels/GPU, 2 fascicles, %d atoms x %d measurements" % (V, N, M),
-                          "voxels_per_gpu": V, "global_voxels": world * V, "atoms": N, "measurements": M,
+               "config": {"workload": "C2: %d voxels%s, 2 fascicles, %d atoms x %d measurements"
+                                      % (a.voxels, "/GPU" if a.scaling == "weak" else " in total", N, M),
+                          "voxels_per_gpu": global_V // world, "global_voxels": global_V, "atoms": N, "measurements": M,
                           "sharding": "voxel shards, no data-path collective; dictionary broadcast once over RCCL"},
                "roofline": roof, "cpu_baseline": cpu}
+        res.update(extras)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
@@ -206,18 +263,104 @@ def main():
     return res
 
 
-def cpu_baseline(sch, ms, d_Y, peaks_h, d_out, nsample):
+def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev, lib, screen):
+    """The rest of the story in the same process, a few steps each (N = 1 only): the FP64 kernel on the same voxels,
+    BASELINE configs 4 and 1, and the PCIe-inclusive rate of the host entry point."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    # ---- FP64 kernel (same arithmetic as the reference's Gram, on FP64 MFMA) on the bench voxels; outputs must be identical
+    if screen:
+        ref_out = d_out.clone()
+        o2 = torch.zeros_like(d_out)
+        lib.mfx_debug_set_k2_screen(0)
+        try:
+            dt, kms = timed(lambda: L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_peaks.data_ptr(), 2, 0, 0, None,
+                                                                 None, 0, V, o2.data_ptr(), st)), 2, 1, dev, lib)
+        finally:
+            lib.mfx_debug_set_k2_screen(1)
+        ach = FLOP_PER_VOXEL * V / ((kms or dt * 1e3) * 1e-3) / 1e12
+        out["fp64_kernel"] = {"value": round(V / dt, 1), "unit": "voxels/s", "kernel": "mfx_fit_k2_kernel<50,false,true,8,2,2>",
+                              "kernel_ms": round(kms, 3) if kms else None, "bound": "mfma_f64", "achieved_TFLOPs": round(ach, 2),
+                              "peak_TFLOPs": PEAK_FP64_MFMA_TFLOPS, "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4),
+                              "outputs_identical_to_default_path": bool(torch.equal(o2, ref_out))}
+    # ---- config 4: two fascicles + CSF + EAR, sub-dictionaries [782, 782, 1, 10] (20 000 voxels: the class is ~30x slower)
+    V4 = min(V, 20000)
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3.0e-9)
+    sig_ear = np.ascontiguousarray(np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * D) for D in np.linspace(0.2e-9, 1.2e-9, C4_E)], axis=1))
+    xcols = np.concatenate([sig_csf[:, None], sig_ear[:, 3:4]], axis=1)
+    _, d_pk4, d_Y4 = synth_voxels(plan, V4, N, M, dev, 2, K=2, extra_cols=xcols)
+    d_csf, d_ear = torch.from_numpy(sig_csf).to(dev), torch.from_numpy(sig_ear).to(dev)
+    o4 = torch.zeros((V4, engine.num_params(2, True, True)), dtype=torch.float64, device=dev)
+    dt, kms = timed(lambda: L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y4.data_ptr(), d_pk4.data_ptr(), 2, 1, 1, d_csf.data_ptr(),
+                                                         d_ear.data_ptr(), C4_E, V4, o4.data_ptr(), st)), 2, 1, dev, lib)
+    ach = FLOP_PER_VOXEL_C4 * V4 / dt / 1e12
+    out["c4"] = {"workload": "C4: %d voxels, 2 fascicles + CSF + EAR, sub-dictionaries [782, 782, 1, %d], %d measurements" % (V4, C4_E, M),
+                 "value": round(V4 / dt, 1), "unit": "voxels/s", "kernel": "mfx_fit_k2x_kernel<50,false,8,2>", "bound": "valu_f64",
+                 "flop_per_voxel": FLOP_PER_VOXEL_C4, "achieved_TFLOPs": round(ach, 2), "peak_TFLOPs": PEAK_FP64_VALU_TFLOPS,
+                 "frac": round(ach / PEAK_FP64_VALU_TFLOPS, 4), "exhaustive_pass_voxels": int(lib.mfx_debug_last_fallback_count())}
+    # ---- config 1: 1 000 voxels, one fascicle, 100 atoms x 60 measurements (the reference's CPU-runnable plumbing case)
+    sch1, dic1, _ = synth.make_model("C1")
+    ms1 = mfu.init_PGSE_multishell_interp(dic1, sch1, np.array([0.0, 0.0, 1.0]))
+    ms1.device = dev.index or 0
+    plan1 = engine.Plan(ms1.device_tables(), scheme=sch1)
+    V1, M1, N1 = 1000, sch1.shape[0], ms1.num_subs
+    _, d_pk1, d_Y1 = synth_voxels(plan1, V1, N1, M1, dev, 0, K=1)
+    o1 = torch.zeros((V1, engine.num_params(1, False, False)), dtype=torch.float64, device=dev)
+    dt, kms = timed(lambda: L.check(lib.mfx_fit_batch_dev(plan1.handle(), d_Y1.data_ptr(), d_pk1.data_ptr(), 1, 0, 0, None, None, 0,
+                                                         V1, o1.data_ptr(), st)), 20, 3, dev, lib)
+    byt = (M1 * 8 + 24 + 5 * 8) * V1
+    out["c1"] = {"workload": "C1: %d voxels, 1 fascicle, %d atoms x %d measurements" % (V1, N1, M1), "value": round(V1 / dt, 1),
+                 "unit": "voxels/s", "kernel": "mfx_fit_small_kernel<false>", "kernel_us": round(kms * 1e3, 1) if kms else None,
+                 "bound": "launch latency (one 1000-workgroup launch; HBM roofline for reference)",
+                 "achieved_GBps": round(byt / dt / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS, "frac": round(byt / dt / 1e9 / PEAK_HBM_GBPS, 6)}
+    # ---- PCIe-inclusive: the host entry point (pinned double-buffered upload overlapped with the kernels), NumPy buffers in and out
+    Yh, pkh = d_Y.cpu().numpy(), np.ascontiguousarray(peaks_h)
+    Kh = np.full(V, 2, dtype=np.int32)
+    engine.fit_batch(plan, Yh[:4096], Kh[:4096], None, None, pkh[:4096], 2, False, False)    # staging buffers, streams
+    t0 = time.perf_counter()
+    ph = engine.fit_batch(plan, Yh, Kh, None, None, pkh, 2, False, False)
+    dt = time.perf_counter() - t0
+    out["host_api"] = {"value": round(V / dt, 1), "unit": "voxels/s", "what": "mfx_fit_batch_rows on host ndarrays (H2D + kernels + D2H)",
+                       "ms": round(dt * 1e3, 2), "outputs_identical_to_device_path": bool(np.array_equal(ph, d_out.cpu().numpy()))}
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(sch, ms, d_Y, peaks_h, d_out, V, nsample):
     """Time the CPU oracle (compiled restatement of the reference algorithm) on a bounded sample of
-    the same voxels, on the host cores of this box, and check the GPU result against it."""
+    the same voxels, on ALL host cores of this box (one worker per core: the analogue of the reference's
+    mp.Pool(cpu_count), mf.py:980-988) and on one core (parallel=False), and check the GPU result against it."""
     from oracle import oracle as orc
-    nthreads = max(1, min(16, os.cpu_count() or 1, orc.max_threads()))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    nthreads = max(1, min(cores, orc.max_threads()))
+    if nsample <= 0:
+        nsample = 40 * nthreads           # ~20 voxels/s/core: about 2 s of wall clock per leg, whatever the box
+    nsample = min(nsample, V)
     T = {"S": ms.S, "N": ms.num_subs, "G_un": ms.Gms_un, "off": ms.off, "x": ms.x_flat, "Y": ms.Y_flat}
     Ys = d_Y[:nsample].cpu().numpy()
     pk = np.ascontiguousarray(peaks_h[:nsample])
     K = np.full(nsample, 2, dtype=np.int32)
     z = np.zeros(nsample, dtype=np.uint8)
-    # one-thread leg (reference parallel=False) on a smaller slice, all-threads leg (mp.Pool analogue)
-    n1 = max(8, nsample // 16)
+    n1 = min(nsample, 48)
     t0 = time.perf_counter()
     orc.fit_batch(T, sch, Ys[:n1], K[:n1], z[:n1], z[:n1], pk[:n1], 2, False, False, None, None, 0, nthreads=1)
     t1 = time.perf_counter()
@@ -226,8 +369,9 @@ def cpu_baseline(sch, ms, d_Y, peaks_h, d_out, nsample):
     got = d_out[:nsample].cpu().numpy()
     ids_equal = bool(np.array_equal(got[:, 3:5], ref[:, 3:5]))
     relerr = float(np.max(np.abs(got[:, :3] - ref[:, :3]) / np.maximum(np.abs(ref[:, :3]), 1e-300)))
-    return {"value": round(nsample / (t2 - t1), 2), "unit": "voxels/s", "cores": nthreads, "kind": "port",
-            "sample": "%d voxels of the same workload, %d OpenMP threads (mp.Pool analogue); "
+    return {"value": round(nsample / (t2 - t1), 2), "unit": "voxels/s", "cores": nthreads, "cores_total": os.cpu_count(),
+            "cpu_model": cpu_model(), "kind": "port",
+            "sample": "%d voxels of the same workload, %d OpenMP threads = one per usable host core (mp.Pool analogue); "
                       "single-thread leg: %d voxels" % (nsample, nthreads, n1),
             "single_thread_value": round(n1 / (t1 - t0), 3),
             "parity_on_sample": {"atom_ids_equal": ids_equal, "max_rel_err_weights": relerr}}

@@ -38,6 +38,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
+#define MFX_S_BOUND 0x40000000   // ring entry flag (in .j): .score is an upper bound (interval bound, single atom), not S(c~)
+#define MFX_S_GUARD 0.25    // run-time guard: an exactly evaluated pair whose screening score was off by more than this
+                            // fraction of the margin DC |y|^2 sends the voxel to the FP64 kernel (and is counted)
 
 // bit pattern of max(x, +0): non-negative doubles order like unsigned integers (LDS atomicMax)
 __device__ __forceinline__ unsigned long long mfx_nonneg_bits(double x) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       s_t0f[idx] = (float)ts;
     }
   }
-  if (tid == 0) { s_cnt[0] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
   if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
 
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           const int slot = s_cnt[0]++;
           s_cand[slot].score = s + mrg;   // exact single-atom score up to the statistics' rounding: evaluated only if it can win
           s_cand[slot].i = k ? 0 : n;
-          s_cand[slot].j = k ? n : 0;
+          s_cand[slot].j = (k ? n : 0) | MFX_S_BOUND;
         }
       }
       // single-atom scores are exact: a pair matters only if S(c) >= best1, i.e. S(c~) >= best1 - mrg
@@ -479,7 +482,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             const double den = fma(-c, c, 1.0);
             const double num = fma(z2, e2, z1 * e1);
             const bool pos = (e1 > -etol) & (e2 > -etol);      // false for padded atoms (z = -inf)
-            const bool wellc = (den >= MFX_S_DENMIN) & (c > -0.5);
+            // (dS/dc = -2 w1 w2 <= |y|^2 needs c >= 0; pairs at an obtuse angle - no physical dictionary has them -
+            // go through the interval bound like the ill-conditioned ones)
+            const bool wellc = (den >= MFX_S_DENMIN) & (c >= 0.0);
             const bool hit = pos & wellc & (fma(-thr, den, num) >= 0.0);
             const bool near = pos & !wellc;
             if (!__any(hit | near)) continue;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
               thr = smax - 2.0 * mrg;
               if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
             }
-            if ((hit | near) && S >= thr) push(S, i, j);
+            if ((hit | near) && S >= thr) push(S, i, hit ? j : (j | MFX_S_BOUND));
           }
         }
       }
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         if (s2 > sb || (s2 == sb && n2 < nb)) { sb = s2; nb = n2; }
       }
       s_cnt[3] = -1;
-      if (sb > 0.0) { s_cnt[3] = s_cnt[0] & (a.scap - 1); push(sb + mrg, nb, 0); }   // [3]: its slot (diagnostics)
+      if (sb > 0.0) { s_cnt[3] = s_cnt[0] & (a.scap - 1); push(sb + mrg, nb, MFX_S_BOUND); }   // [3]: its slot (diagnostics)
     }
     __syncthreads();
   }
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       // fetch the rows side by side, then five lanes run the five sequential sums of mf_utils.py:307-325 from LDS.
       for (int e = wave; e < neval; e += NW) {
         const int cix = s_evl[e];
-        const int i = s_cand[cix].i, j = s_cand[cix].j;
+        const int i = s_cand[cix].i, jf = s_cand[cix].j, j = jf & ~MFX_S_BOUND;
 #pragma unroll
         for (int mb = 0; mb < (MP + 63) / 64; ++mb) {   // all table loads of the pair in flight at once
           const int m = mb * 64 + lane;
@@ -830,6 +835,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         nnls2_exact(y_sq, a11, a12, a22, y1, y2, u0, u1, r);
         const long ix = (long)i * N + j;
         if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+        // run-time guard on the screening error (wave-uniform values)
+        if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0 && fabs((y_sq - r) - s_cand[cix].score) > MFX_S_GUARD * mrg) s_cnt[1] = 1;
 #ifdef MFX_STAMPS
         if (lane == 0) {
           ++dbg_eval;
@@ -842,10 +849,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       for (int e = tid; e < neval; e += WG) {
         const int cix = s_evl[e];
         double r, u0, u1;
-        const int i = s_cand[cix].i, j = s_cand[cix].j;
+        const int i = s_cand[cix].i, jf = s_cand[cix].j, j = jf & ~MFX_S_BOUND;
         exact_pair(i, j, u0, u1, r);
         const long ix = (long)i * N + j;
         if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
+        if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0 && fabs((y_sq - r) - s_cand[cix].score) > MFX_S_GUARD * mrg) s_cnt[1] = 1;
 #ifdef MFX_STAMPS
         ++dbg_eval;
         if (cix >= 1 && cix != s_cnt[3] && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
@@ -864,6 +872,16 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #endif
     block_argmin(res, idx, w0, w1);
     MFX_STAMP(14);
+  }
+  if (s_cnt[1]) {   // workgroup-uniform (block_argmin ends with a barrier)
+    // the split-FP16 Gram missed an exactly evaluated pair by more than the guard allows: do not trust the short
+    // list, let the FP64 kernel redo the voxel
+    if (tid == 0) {
+      const int slot = atomicAdd(a.fb_count, 1);
+      a.fb_list[slot] = vox;
+      atomicAdd(a.fb_count + 1, 1);
+    }
+    return;
   }
   // near-zero second weight: evaluate the winner's whole row / column family exactly (see fit_k2.hip)
   for (int pass = 0; pass < 2; ++pass) {

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 outputs of a profiling session (gpurun_out/prof_stats, gpurun_out/prof_pmc_*) into the
 files kept under profiles/ (kernel stats CSV head + PMC summary JSON for the dominant kernel).
-    python tools/profile_summary.py [kernel-name-substring] [tag]"""
+    python tools/profile_summary.py [kernel-name-substring] [tag] [round]"""
 import collections, csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kern = sys.argv[1] if len(sys.argv) > 1 else "mfx_fit_k2s_kernel"
 tag = sys.argv[2] if len(sys.argv) > 2 else "k2s"
+rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 res = collections.defaultdict(float)
 # gpurun merges new outputs into gpurun_out/ without removing older ones: take the newest run of every counter group
 for d in glob.glob(R + '/gpurun_out/prof_pmc_*/runc'):
@@ -19,7 +20,7 @@ V = 100000
 fetch_raw = res['FETCH_SIZE'] * 1024.0
 write = res['WRITE_SIZE'] * 1024.0
 cyc_xcd = res['GRBM_GUI_ACTIVE'] / 8
-out = {"round": 1,
+out = {"round": rnd,
        "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                   "--no-cpu-baseline (one pass per counter group; FETCH_SIZE and WRITE_SIZE in separate passes)",
        "kernel": kern, "voxels_per_launch": V, "counters": dict(res),
@@ -34,16 +35,16 @@ out = {"round": 1,
        "kernel_cycles_per_xcd": cyc_xcd, "cu_cycles_per_voxel": cyc_xcd * 256 / V,
        "mfma_pipe_utilisation": res['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc_xcd,
        "valu_insts_per_mfma": res['SQ_INSTS_VALU'] / max(res['SQ_INSTS_MFMA'], 1)}
-json.dump(out, open(R + '/profiles/r01_pmc_traffic_%s.json' % tag, 'w'), indent=1)
+json.dump(out, open(R + '/profiles/r%02d_pmc_traffic_%s.json' % (rnd, tag), 'w'), indent=1)
 ks = sorted(glob.glob(R + '/gpurun_out/prof_stats/runc/*_kernel_stats.csv'), key=os.path.getmtime)
 if ks:
     rows = list(csv.reader(open(ks[-1])))
-    with open(R + '/profiles/r01_kernel_stats_%s.csv' % tag, 'w') as f:
+    with open(R + '/profiles/r%02d_kernel_stats_%s.csv' % (rnd, tag), 'w') as f:
         w = csv.writer(f)
         for r in rows[:6]:
             r = list(r); r[0] = r[0][:120]
             w.writerow(r)
-for src, dst in (("bench_final.json", "r01_bench_%s.json" % tag), ("prof_stats_bench.json", "r01_bench_%s_under_rocprof.json" % tag)):
+for src, dst in (("bench_final.json", "r%02d_bench_%s.json" % (rnd, tag)), ("prof_stats_bench.json", "r%02d_bench_%s_under_rocprof.json" % (rnd, tag))):
     if os.path.exists(R + '/gpurun_out/' + src):
         shutil.copy(R + '/gpurun_out/' + src, R + '/profiles/' + dst)
 print(json.dumps({k: v for k, v in out.items() if k not in ("command", "counters")}, indent=1))
