@@ -155,6 +155,10 @@ void mfx_debug_set_stamps(void* dev_ptr);
  * for that copy (the fit calls themselves never do).  ..._guard_count: how many of them the screening-error guard sent. */
 int mfx_debug_last_fallback_count(void);
 int mfx_debug_last_guard_count(void);
+/* Diagnostic: raw counter `which` of the last call: 0 hand-backs / exhaustive passes, 1 guard hand-backs, and for the
+ * two-fascicle + CSF/EAR kernel 2 short-listed pairs, 3 family items (one-atom / no-atom supports and ambiguous slots
+ * evaluated exactly), summed over the batch. */
+int mfx_debug_last_counter(int which);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs

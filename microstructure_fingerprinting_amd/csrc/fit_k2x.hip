@@ -18,7 +18,9 @@
 //     active atoms ties (a voxel fitted by one fascicle + CSF, a pure CSF voxel ...), so the exact stage evaluates the
 //     whole family in the reference's arithmetic and scan order - as the reference's strict-'<' first hit demands -
 //     instead of letting the ties flood the short list (one entry per slot and round: that list used to overflow and
-//     drop entries silently);
+//     drop entries silently).  When NO fascicle atom is active the tuples (i1, i2, t) of a given t all get the very
+//     same arithmetic in the reference (its 2-variable fall-backs then depend on the extra column only), so the first
+//     of them, (0, 0, t), stands for all; any tuple in which an atom does help is in the pair list or an atom family;
 //   * every short-listed pair is evaluated exactly for ALL its extra tuples t (they tie when the extra column is inactive);
 //   * a short list that still overflows triggers the exhaustive exact pass over all N*N*ntup tuples (slow, exact by
 //     construction, counted in the launch's overflow counter).
@@ -46,12 +48,12 @@ struct FitK2XArgs {
   int num_params, maxfasc, csf_on, ear_on;
   int vox_base;  // first voxel (or first vox_list entry) of this launch
   int maxc;      // short-list size beyond which the exhaustive exact pass runs (MFX_XMAXC; tests lower it)
-  int* ovf_count;  // [0] voxels that took the exhaustive pass (null: not counted)
+  int* ovf_count;  // [4] launch counters: [0] voxels that took the exhaustive pass, [2] short-listed pairs, [3] family items
 };
 
 #define MFX_XFAM 64   // family items (see below) per voxel before the exhaustive pass takes over
 struct FamX {
-  int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (all i, all j, t)   4: (i, j = lc mod 16, all t)
+  int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (0, 0, t): no fascicle atom active   4: (i, j = lc mod 16, all t)
   int a, t;
 };
 
@@ -386,6 +388,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
   // (a voxel in which no support scores above zero keeps the reference's initial state: nothing to evaluate)
   const bool nothing = !(gmax_run > 0.0);
+  if (tid == 0 && a.ovf_count) {   // diagnostics: short-listed pairs and family items of the launch
+    atomicAdd(a.ovf_count + 2, ncand);
+    atomicAdd(a.ovf_count + 3, nfam_app);
+  }
   const bool exhaustive = !nothing && (a.maxc == 0 || nappend > a.maxc || nfam_app > MFX_XFAM);   // workgroup-uniform
   __syncthreads();
   // scratch inside the (now idle) B buffers
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       const int type = s_fam[f].type, fa = s_fam[f].a, ft = s_fam[f].t;
       if (type == 1) { for (int n = tid; n < N; n += WG) consider(fa, n, ft); }
       else if (type == 2) { for (int n = tid; n < N; n += WG) consider(n, fa, ft); }
-      else if (type == 3) { for (long q = tid; q < (long)N * N; q += WG) consider((int)(q / N), (int)(q % N), ft); }
+      else if (type == 3) { if (tid == 0) consider(0, 0, ft); }
       else {   // 4: row fa, columns ft, ft + 16, ...: the (lane,row) slot of the scan, all extra tuples
         const int ncol = (N - ft + 15) / 16;
         for (int q = tid; q < ncol * ntup; q += WG) consider(fa, ft + 16 * (q / ntup), q % ntup);

@@ -116,6 +116,7 @@ extern "C" double mfx_last_kernel_ms(void) {
 }
 extern "C" int mfx_debug_last_fallback_count(void) { return fb_read(0); }
 extern "C" int mfx_debug_last_guard_count(void) { return fb_read(1); }
+extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < 4) ? fb_read(which) : -1; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { mfx_thread().k2_screen = enabled ? 1 : 0; }
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (unsigned long long*)dev_ptr; }
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }

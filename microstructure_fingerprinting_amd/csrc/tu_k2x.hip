@@ -35,7 +35,7 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
   }
   HIPCHK(hipGetLastError());
   if (int rc = mfx_prof_end(st)) return rc;
-  return mfx_fb_accumulate(cnt.as<int>(), 1, st);
+  return mfx_fb_accumulate(cnt.as<int>(), 4, st);
 }
 
 int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {

@@ -22,7 +22,13 @@ def run(name, cfg, V, K, c, e, E=10, N=None, bracket=False):
     sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3e-9)
     sig_ear = np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * x) for x in np.linspace(0.2e-9, 1.2e-9, E)], axis=1)
     peaks = np.concatenate([synth.unit_vectors(rng, V) for _ in range(max(K, 1))], axis=1)
-    Y = 500 * dic[:, rng.integers(0, dic.shape[1], V)].T * rng.uniform(0.5, 1, (V, 1)) + rng.normal(0, 500 / 30, (V, M))
+    if os.environ.get("MFX_DEV_MIX"):   # every compartment of the class present (Dirichlet fractions), atoms rotated to the peaks: bench.py's recipe
+        import bench
+        xc = np.concatenate(([sig_csf[:, None]] if c else []) + ([sig_ear[:, 3:4]] if e else []), axis=1) if (c or e) else None
+        _, dpk_, dY_ = bench.synth_voxels(plan, V, Na, M, torch.device("cuda", 0), 5, K=max(K, 1), extra_cols=xc)
+        Y, peaks = dY_.cpu().numpy(), dpk_.cpu().numpy()
+    else:
+        Y = 500 * dic[:, rng.integers(0, dic.shape[1], V)].T * rng.uniform(0.5, 1, (V, 1)) + rng.normal(0, 500 / 30, (V, M))
     dY = torch.from_numpy(Y).cuda(); dpk = torch.from_numpy(peaks).cuda()
     dcsf = torch.from_numpy(sig_csf).cuda(); dear = torch.from_numpy(np.ascontiguousarray(sig_ear)).cuda()
     npar = engine.num_params(K, c, e)
@@ -34,13 +40,15 @@ def run(name, cfg, V, K, c, e, E=10, N=None, bracket=False):
         L.check(lib.mfx_fit_batch_dev(plan.handle(), dY.data_ptr(), dpk.data_ptr(), K, c, e, dcsf.data_ptr() if c else None,
                                       dear.data_ptr() if e else None, E if e else 0, V, out.data_ptr(), st))
         torch.cuda.synchronize(); t1 = time.time()
-    print("%-44s V=%6d N=%4d M=%3d: %8.2f ms -> %10.0f voxels/s" % (name, V, Na, M, (t1 - t0) * 1e3, V / (t1 - t0)), flush=True)
+    cn = [lib.mfx_debug_last_counter(q) for q in range(4)]
+    print("%-44s V=%6d N=%4d M=%3d: %8.2f ms -> %10.0f voxels/s   counters %s" % (name, V, Na, M, (t1 - t0) * 1e3, V / (t1 - t0), cn), flush=True)
 
-run("C1: K=1 [100]", "C1", 100000, 1, 0, 0)
-run("K=1 [782]", "C2", 100000, 1, 0, 0)
-run("K=1 [782,1,10]", "C2", 100000, 1, 1, 1)
-run("C2: K=2 [782,782]", "C2", 100000, 2, 0, 0)
-run("K=2 [782,782], 105-row bracketed protocol", "C2", 100000, 2, 0, 0, bracket=True)
+if not os.environ.get("MFX_DEV_K2X_ONLY"):
+    run("C1: K=1 [100]", "C1", 100000, 1, 0, 0)
+    run("K=1 [782]", "C2", 100000, 1, 0, 0)
+    run("K=1 [782,1,10]", "C2", 100000, 1, 1, 1)
+    run("C2: K=2 [782,782]", "C2", 100000, 2, 0, 0)
+    run("K=2 [782,782], 105-row bracketed protocol", "C2", 100000, 2, 0, 0, bracket=True)
 run("K=2+CSF [782,782,1]", "C2", 10000, 2, 1, 0)
 run("K=2+EAR [782,782,10]", "C2", 4000, 2, 0, 1)
 run("C4: K=2+CSF+EAR [782,782,1,10]", "C2", 4000, 2, 1, 1)
