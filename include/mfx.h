@@ -161,6 +161,10 @@ int mfx_debug_last_guard_count(void);
 int mfx_debug_last_counter(int which);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
+/* Diagnostic: 1 routes two-fascicle voxels of protocols with 129..256 measurements to the wide (one wave per SIMD)
+ * screening kernel instead of the two-waves-per-SIMD one, 0 never uses the wide kernel (protocols of more than 256
+ * measurements then run on the FP64 kernel), any other value: automatic (same as MFX_K2_WIDE in the environment). */
+void mfx_debug_set_k2_wide(int mode);
 /* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs
  * (default and maximum 256; 0 forces that pass for every voxel -- used by the tests to cover it). */
 void mfx_debug_set_k2_maxc(int maxc);

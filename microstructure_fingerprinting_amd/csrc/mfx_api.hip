@@ -118,6 +118,7 @@ extern "C" int mfx_debug_last_fallback_count(void) { return fb_read(0); }
 extern "C" int mfx_debug_last_guard_count(void) { return fb_read(1); }
 extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < 4) ? fb_read(which) : -1; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { mfx_thread().k2_screen = enabled ? 1 : 0; }
+extern "C" void mfx_debug_set_k2_wide(int mode) { mfx_thread().k2_wide = mode == 1 ? 1 : (mode == 0 ? 0 : 2); }
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (unsigned long long*)dev_ptr; }
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
 extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }
@@ -419,20 +420,43 @@ size_t mfx_k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 
+size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL) {
+  const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
+  return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP +
+         4 * 4 * TL * 64 + (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
+}
+
+// Which kernel serves a two-fascicle class:
+//   M <= 256: the two-waves-per-SIMD screening kernel (fit_k2s.hip), or - MFX_K2_WIDE=1 / mfx_debug_set_k2_wide(1) - the
+//             wide one (fit_k2w.hip, KS = 13 / 16);
+//   256 < M <= 560: the wide screening kernel (KS = 24 / 35; the long A tile needs its one-wave-per-SIMD register file);
+//   otherwise, with MFX_K2_SCREEN=0, or when the images do not fit the LDS: the FP64 kernel (fit_k2.hip).
 static int launch_k2(const FitK2Args& a, int nvox, hipStream_t st) {
   MfxThread& T = mfx_thread();
   if (T.k2_screen < 0) { const char* e = getenv("MFX_K2_SCREEN"); T.k2_screen = (e && e[0] == '0') ? 0 : 1; }
+  if (T.k2_wide < 0) { const char* e = getenv("MFX_K2_WIDE"); T.k2_wide = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2; }   // 2: automatic
   const int M = a.P.M;
-  const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
-  if (T.k2_screen && M <= 256 && mfx_k2_f64_fits(a)) {
-    const bool br = a.P.any_bracket != 0;
-    // three chunk images (one barrier per chunk) where they fit into the 160 KB of LDS, else two
-    const int NB = (T.k2s_nb != 2 && mfx_k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (mfx_k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);
-    if (NB) {
-      if (KSm == 4) return mfx_launch_k2s_ks4(a, nvox, st, br, NB);
-      if (KSm == 8) return mfx_launch_k2s_ks8(a, nvox, st, br, NB);
-      if (KSm == 13) return mfx_launch_k2s_ks13(a, nvox, st, br, NB);
-      return mfx_launch_k2s_ks16(a, nvox, st, br, NB);
+  const bool br = a.P.any_bracket != 0;
+  if (T.k2_screen && mfx_k2_f64_fits(a)) {
+    const bool wide_ok = T.k2_wide != 0;
+    if (M > 256 && M <= 560 && wide_ok) {
+      if (M <= 384 && mfx_k2w_lds_bytes(24, a.T.N, br, 1, 1) <= 160 * 1024) return mfx_launch_k2w_ks24(a, nvox, st, br);
+      if (mfx_k2w_lds_bytes(35, a.T.N, br, 1, 1) <= 160 * 1024) return mfx_launch_k2w_ks35(a, nvox, st, br);
+    }
+    if (M <= 256) {
+      if (T.k2_wide == 1 && M > 128) {
+        if (M <= 208 && mfx_k2w_lds_bytes(13, a.T.N, br, 2, 2) <= 160 * 1024) return mfx_launch_k2w_ks13(a, nvox, st, br);
+        if (mfx_k2w_lds_bytes(16, a.T.N, br, 2, 2) <= 160 * 1024) return mfx_launch_k2w_ks16(a, nvox, st, br);
+      }
+      const int KSm = M <= 64 ? 4 : (M <= 128 ? 8 : (M <= 208 ? 13 : 16));   // k-steps of 16 measurements
+      // three chunk images (one barrier per chunk) where they fit into the 160 KB of LDS, else two
+      const int NB = (T.k2s_nb != 2 && mfx_k2s_lds_bytes(KSm, a.T.N, br, 3) <= 160 * 1024) ? 3 : (mfx_k2s_lds_bytes(KSm, a.T.N, br, 2) <= 160 * 1024 ? 2 : 0);
+      if (NB) {
+        if (KSm == 4) return mfx_launch_k2s_ks4(a, nvox, st, br, NB);
+        if (KSm == 8) return mfx_launch_k2s_ks8(a, nvox, st, br, NB);
+        if (KSm == 13) return mfx_launch_k2s_ks13(a, nvox, st, br, NB);
+        return mfx_launch_k2s_ks16(a, nvox, st, br, NB);
+      }
     }
   }
   if (int rc = mfx_launch_k2_f64(a, nvox, st, true)) return rc;

@@ -30,6 +30,7 @@ struct MfxThread {
   int k2s_nb = 0;          // 0: as many chunk images as fit; 2: force the two-image schedule
   int k2s_cap = 0;         // 0: MFX_S_CAP
   int k2_screen = -1;      // MFX_K2_SCREEN=0 disables the screening kernels
+  int k2_wide = -1;        // MFX_K2_WIDE: 1 forces the wide screening kernel (fit_k2w.hip) wherever it applies, 0 never uses it
   // hand-back counters of the last mfx_fit_batch* call: summed on the device over its launches, copied to pinned memory
   // behind the kernels and read only when somebody asks (mfx_debug_last_*_count): the _dev entry points never synchronise
   int* fb_dev = nullptr;           // device [4]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
@@ -97,5 +98,11 @@ int mfx_launch_k2s_ks4(const FitK2Args& a, int nvox, hipStream_t st, bool br, in
 int mfx_launch_k2s_ks8(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
 int mfx_launch_k2s_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
 int mfx_launch_k2s_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
+// wide screening kernel (tu_k2w_*.hip): one wave per SIMD, TL row tiles per wave (fit_k2w.hip)
+size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL);
+int mfx_launch_k2w_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
+int mfx_launch_k2w_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br);
+int mfx_launch_k2w_ks24(const FitK2Args& a, int nvox, hipStream_t st, bool br);
+int mfx_launch_k2w_ks35(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 // two fascicles + CSF/EAR (tu_k2x.hip)
 int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st);

@@ -1,0 +1,3 @@
+// tu_k2w_ks35.hip -- wide screening kernel, M <= 560: one row tile per wave, one chunk image
+#include "k2w_launch.h"
+MFX_K2W_TU(35, 1, 1, mfx_launch_k2w_ks35)

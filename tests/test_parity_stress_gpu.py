@@ -371,3 +371,96 @@ def test_dev_entry_point_is_asynchronous_and_reports_bad_directions():
     host = engine.fit_batch(plan, Y, np.ones(V, int), np.ones(V, bool), np.ones(V, bool), peaks[:, :3], 1, True, True,
                             sig_csf, sig_ear, 2)
     assert np.array_equal(out.cpu().numpy(), host)
+
+
+def _c2_like_voxels(rng, plan, N, V):
+    from microstructure_fingerprinting_amd import synth
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    q = V // 10
+    p2[:q] = _second_peak(rng, p1[:q], 3.0)
+    p2[q:q + q // 2] = p1[q:q + q // 2]
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(2), V)
+    nu[2 * q:3 * q] = [1.0, 0.0]
+    nu[3 * q:3 * q + q // 2] = [0.0, 1.0]
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:] * _rotate_cols(plan, p2, atoms[:, 1]))
+    noise = rng.normal(0, 500.0 / 30.0, Y.shape)
+    noise[4 * q:4 * q + q // 2] = 0.0
+    return np.concatenate([p1, p2], axis=1), Y + noise
+
+
+@pytest.mark.parametrize("N,shells,dirs", [(782, [1000, 2000, 3000], [66, 66, 66]), (100, [1000, 2000, 3000], [66, 66, 66]),
+                                            (33, [1000, 2000], [70, 80]), (416, [1000, 2000, 3000, 4000], [60, 60, 60, 60])])
+def test_k2_wide_kernel_vs_default_and_oracle(N, shells, dirs):
+    """The wide screening kernel (fit_k2w.hip: one wave per SIMD, two row tiles per wave) forced onto protocols of 129..256
+    measurements: outputs bit-identical to the default two-waves-per-SIMD screening kernel on 6 000 voxels (close
+    crossings, identical peaks, one fascicle, noise-free included), and equal to the oracle on a sample; ragged
+    dictionary sizes (one tile + tail, partial rounds)."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(900 + N)
+    sch = synth.make_scheme(rng, 2, shells, dirs)
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    V = 6000
+    peaks, Y = _c2_like_voxels(rng, plan, N, V)
+    lib = L.lib()
+    K = np.full(V, 2)
+    res = []
+    try:
+        for wide in (1, 0):
+            lib.mfx_debug_set_k2_wide(wide)
+            res.append(engine.fit_batch(plan, Y, K, None, None, peaks, 2, False, False))
+    finally:
+        lib.mfx_debug_set_k2_wide(-1)
+    bad = np.where(np.any(res[0] != res[1], axis=1))[0]
+    assert bad.size == 0, "wide kernel differs from the default kernel in voxels %s" % bad[:10]
+    ns = 48
+    sel = np.arange(0, V, V // ns)[:ns]
+    z = np.zeros(ns, bool)
+    ref = orc.fit_batch(_tables(ms), sch, Y[sel], K[:ns], z, z, peaks[sel], 2, False, False, None, None, 0, nthreads=NTHREADS)
+    _assert_rows(res[0][sel], ref, 2, "wide kernel N=%d" % N)
+
+
+@pytest.mark.parametrize("N,dirs,bracket", [(782, [100, 100, 100], False), (782, [137, 137, 137, 137], False),
+                                             (100, [137, 137, 137, 137], True), (65, [90, 90, 90], True)])
+def test_k2_long_protocols_wide_kernel_vs_fp64_kernel_and_oracle(N, dirs, bracket):
+    """Protocols of 257..560 measurements (the reference's HCP-MGH fixture has 552 rows) run on the wide screening kernel
+    (one row tile per wave, KS = 24 / 35): bit-identical to the FP64 kernel on 3 000 voxels, equal to the oracle on a
+    sample; exact-G and G-bracketed rows."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(700 + N + len(dirs))
+    shells = [1000, 2000, 3000, 5000][:len(dirs)]
+    sch_ms = synth.make_scheme(rng, 2, shells, dirs)
+    dic = synth.make_dictionary(rng, sch_ms, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch_ms, Z)
+    sch = sch_ms.copy()
+    if bracket:
+        nz = np.where(sch[:, 3] > 0)[0]
+        Gs = ms["Gms_un"]
+        sch[nz[::3], 3] = rng.choice([0.4 * Gs[1] + 0.6 * Gs[2], 0.5 * (Gs[-2] + Gs[-1])], size=nz[::3].size)
+    plan = ms.plan_for(sch)
+    V = 3000
+    peaks, Y = _c2_like_voxels(rng, plan, N, V)
+    lib = L.lib()
+    K = np.full(V, 2)
+    res = []
+    try:
+        for screen in (1, 0):
+            lib.mfx_debug_set_k2_screen(screen)
+            res.append(engine.fit_batch(plan, Y, K, None, None, peaks, 2, False, False))
+    finally:
+        lib.mfx_debug_set_k2_screen(1)
+    bad = np.where(np.any(res[0] != res[1], axis=1))[0]
+    assert bad.size == 0, "wide kernel differs from the FP64 kernel in voxels %s" % bad[:10]
+    ns = 32
+    sel = np.arange(0, V, V // ns)[:ns]
+    z = np.zeros(ns, bool)
+    ref = orc.fit_batch(_tables(ms), sch, Y[sel], K[:ns], z, z, peaks[sel], 2, False, False, None, None, 0, nthreads=NTHREADS)
+    _assert_rows(res[0][sel], ref, 2, "long protocol M=%d" % sch.shape[0])
