@@ -664,13 +664,24 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       if (ntiles > 1) gen_load(1);
       __syncthreads();
       if (round == 0) MFX_STAMP(4);
+#ifdef MFX_STAMPS_W   // diagnostic: where a chunk's time goes (wave 0, chunks 10 and 11 of round 1), tools/dev_stamps_w.py
+#define MFX_WSTAMP(k) do { if (a.stamps && round == 1 && (c == 10 || c == 11) && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (c - 10) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFX_WSTAMP(k) do { } while (0)
+#endif
       auto chunk = [&](auto pc, int c) {
         const bool do_scr = c >= 1, do_gen = c + 1 < ntiles;
+        MFX_WSTAMP(0);
         if (do_scr) screen_begin(c - 1);
+        MFX_WSTAMP(1);
         mfma_chunk(pc, c & 1, do_scr, do_gen, (c + 1) & 1);
+        MFX_WSTAMP(2);
         if (do_scr) screen_finish(pc, c - 1);
+        MFX_WSTAMP(3);
         if (c + 2 < ntiles) gen_load(c + 2);   // consumed by the slices of chunk c+1
+        MFX_WSTAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: the table loads stay in flight
+        MFX_WSTAMP(5);
       };
       for (int c = 0; c < ntiles; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);

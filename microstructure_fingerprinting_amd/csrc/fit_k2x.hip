@@ -22,9 +22,19 @@
 //     same arithmetic in the reference (its 2-variable fall-backs then depend on the extra column only), so the first
 //     of them, (0, 0, t), stands for all; any tuple in which an atom does help is in the pair list or an atom family;
 //   * every short-listed pair is evaluated exactly for ALL its extra tuples t (they tie when the extra column is inactive);
+//   * in front of the per-tuple scoring (~30 FP64 instructions per tuple) sits a FILTER of 5 instructions per tuple: with
+//     the extra columns R_t = {f, x_t} of tuple t left UNCONSTRAINED the problem is a two-atom problem in the orthogonal
+//     complement of R_t (projected atoms d' = d - proj_R d, projected signal y'), whose score + the score q0_t of R_t alone
+//     is an upper bound of the tuple's NNLS score.  Two positive atom weights with that bound >= T needs
+//     cos(d1', d2') <= cos(theta1 + theta2), theta_i = acos(min(1, z_i' / sqrt(T - q0_t))) - the angle-sum test of
+//     fit_k2s.hip, here with the cross term updated per tuple in FP64 (a12' = a12 - u_f1 u_f2 - u_t1 u_t2: no cancellation
+//     error) and the test itself in FP32 from two constants per (atom, tuple); an atom whose own projected score reaches
+//     T - q0_t passes with every partner.  T = the best NNLS score found so far (workgroup-wide, LDS atomicMax) minus the
+//     tie tolerance: only tuples that pass are scored, typically < 1 %;
 //   * a short list that still overflows triggers the exhaustive exact pass over all N*N*ntup tuples (slow, exact by
 //     construction, counted in the launch's overflow counter).
 #pragma once
+#include "fit_k2.hip"     // mfx_static_for, MFX_STAMP
 #include "fit_small.hip"  // ExtrasDev, mfx_np_sumsq
 #include "mfx_device.h"
 #include "nnls_small.h"
@@ -48,6 +58,8 @@ struct FitK2XArgs {
   int num_params, maxfasc, csf_on, ear_on;
   int vox_base;  // first voxel (or first vox_list entry) of this launch
   int maxc;      // short-list size beyond which the exhaustive exact pass runs (MFX_XMAXC; tests lower it)
+  int xx_in_lds; // the extra columns are staged in LDS (when the 160 KB allow it)
+  unsigned long long* stamps;  // diagnostic builds only: [gridDim.x][16] s_memtime stamps (null otherwise)
   int* ovf_count;  // [4] launch counters: [0] voxels that took the exhaustive pass, [2] short-listed pairs, [3] family items
 };
 
@@ -55,6 +67,16 @@ struct FitK2XArgs {
 struct FamX {
   int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (0, 0, t): no fascicle atom active   4: (i, j = lc mod 16, all t)
   int a, t;
+};
+
+struct ProjC {   // filter constants of one (atom, extra tuple): see the top of the file
+  double u;      // d . x_t' / |x_t'| with x_t' = x_t minus its projection on the fixed column
+  float pn, qn;  // (P + D) |d'|, (1 - D) Q |d'|
+};
+#define MFX_XD 2e-6f   // margin folded into the filter constants: covers the FP32 evaluation of the test
+struct ProjB {   // threshold-independent part of the filter constants of one (atom, extra tuple), computed once per voxel
+  double u;      // as ProjC::u (entry ntup of an atom: its d . f / |f|)
+  float np, zp;  // |d'| (0: d' vanishes, the atom passes with every partner) and d'.y' / |d'|
 };
 
 struct CandX {
@@ -77,7 +99,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   const int ntup = (Kp == 3) ? NX : E;  // extra tuples per (i1,i2)
   const double2* __restrict__ tab = a.T.tab;
   const int vox = a.vox_list ? a.vox_list[a.vox_base + blockIdx.x] : a.vox_base + blockIdx.x;
-  double* __restrict__ wsA = a.ws + (size_t)blockIdx.x * 2 * NP * MFX_XS;  // [k][n][e]
+  double* __restrict__ wsA = a.ws + (size_t)blockIdx.x * 2 * NP * (MFX_XS + 2 * (ntup + 1));  // [k][n][e] atom . extra inner products
+  ProjB* __restrict__ wsP = (ProjB*)(wsA + (size_t)2 * NP * MFX_XS);                            // [k][n][ntup + 1]
 
   double* sB = smem;                              // [NBUF][MP][16]
   double* s_y = sB + NBUF * MP * 16;              // [MP]
@@ -97,23 +120,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double* s_Qx = s_red + 32;                      // [XS]            best support made of extra columns only, per extra tuple
   CandX* s_cand = (CandX*)(s_Qx + MFX_XS);        // [XMAXC]
   FamX* s_fam = (FamX*)(s_cand + MFX_XMAXC);      // [XFAM]
-  int* s_r0 = (int*)(s_fam + MFX_XFAM);           // [2][MP]
+  double* s_tc = (double*)(s_fam + MFX_XFAM);     // [XS][4] per extra tuple: l_t, 1/r_t, y.x_t', q0_t   + [2]: 1/|f|, y.f/|f|
+  double* s_rowf = s_tc + 4 * MFX_XS + 2;         // [NW][16] d1 . f / |f| of each wave's rows
+  double* s_colf = s_rowf + NW * 16;              // [2][16]  d2 . f / |f| of the chunk's columns
+  unsigned long long* s_thr = (unsigned long long*)(s_colf + 2 * 16);   // [2] best NNLS score so far (bits of a non-negative double)
+  ProjC* s_rowc = (ProjC*)(s_thr + 2);            // [NW][16][ntup]
+  ProjC* s_colc = s_rowc + NW * 16 * ntup;        // [2][16][ntup]
+  double* s_xx = (double*)(s_colc + 2 * 16 * ntup);   // [M][NX] the extra columns (read by every row of every sum: LDS, not global loads)
+  int* s_r0 = (int*)(s_xx + (a.xx_in_lds ? (size_t)M * NX : 0));      // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;
   int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);
 
+  MFX_STAMP(0);
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   const double* __restrict__ pk = a.peaks + (size_t)vox * a.peaks_ld;
-  const double* __restrict__ xx = a.X.x;
+  if (a.xx_in_lds) for (int q = tid; q < M * NX; q += WG) s_xx[q] = a.X.x[q];
+  const double* xx = a.xx_in_lds ? s_xx : a.X.x;
   for (int m = tid; m < MP; m += WG) s_y[m] = (m < M) ? yv[m] : 0.0;
   for (int idx = tid; idx < 2 * MP; idx += WG) {
     const int k = idx / MP, m = idx - k * MP;
     RowDesc rd;
     rd.r0 = a.T.P; rd.t0 = 0.0; rd.r1 = -1; rd.t1 = 0.0;
     if (m < M) rd = mfx_row_desc(a.T, a.P, m, pk[3 * k], pk[3 * k + 1], pk[3 * k + 2]);
-    s_r0[idx] = rd.r0;
+    s_r0[idx] = rd.r0 * ldn;            // element offset of the knot row (SGPR base + 32-bit offset addressing)
     s_t0[idx] = rd.t0;
     if (BRACKET) {
-      s_r1[idx] = rd.r1;
+      s_r1[idx] = rd.r1 < 0 ? -1 : rd.r1 * ldn;
       s_t1[idx] = rd.t1;
       if (k == 0) { s_tG[m] = (m < M) ? a.P.tG[m] : 0.0; s_dG[m] = (m < M) ? a.P.dG[m] : 1.0; }
     }
@@ -140,18 +172,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     double q = pos1(s_Gxx[cx * MFX_XS + cx], s_Yx[cx]);
     if (HASF) q = fmax(q, fmax(pos1(s_Gxx[0], s_Yx[0]), pos2(s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], s_Yx[0], s_Yx[cx])));
     s_Qx[tid] = q;
+    // relaxation of tuple t: Gram-Schmidt of its extra columns R_t = {f, x_t} (f only in the four-column class)
+    const double gf = HASF ? s_Gxx[0] : 1.0, rf = sqrt(gf);
+    const double l = HASF ? s_Gxx[cx] / rf : 0.0;
+    const double gtt = s_Gxx[cx * MFX_XS + cx] - l * l;
+    const bool dep = !(gtt > 1e-12 * s_Gxx[cx * MFX_XS + cx]);   // x_t inside span(f): R_t = {f}
+    const double irt = dep ? 0.0 : 1.0 / sqrt(gtt);
+    const double yf = HASF ? s_Yx[0] / rf : 0.0;
+    const double yt = (s_Yx[cx] - yf * l) * irt;
+    s_tc[4 * tid] = l; s_tc[4 * tid + 1] = irt; s_tc[4 * tid + 2] = yt; s_tc[4 * tid + 3] = yf * yf + yt * yt;
+    if (tid == 0) { s_tc[4 * MFX_XS] = HASF ? 1.0 / rf : 0.0; s_tc[4 * MFX_XS + 1] = yf; }
   }
   const double eps_abs_of = 1e-9;
 
+  // table entry at a 32-bit element offset: SGPR base + VGPR offset addressing (64-bit address arithmetic per element
+  // costs several quarter-rate VALU instructions, and beside FP64 MFMAs every VALU instruction counts in full)
+  auto tab_at = [&](int eo) -> double2 { return *(const double2*)((const char*)tab + ((unsigned)eo << 4)); };
   auto elem = [&](int k, int m, int n) -> double {
-    if (BRACKET) {
-      RowDesc rd;
-      rd.r0 = s_r0[k * MP + m]; rd.t0 = s_t0[k * MP + m];
-      rd.r1 = s_r1[k * MP + m]; rd.t1 = s_t1[k * MP + m];
-      return mfx_eval_br(tab, ldn, rd, s_tG[m], s_dG[m], n);
-    } else {
-      return mfx_eval(tab, ldn, s_r0[k * MP + m], s_t0[k * MP + m], n);
+    const double2 e = tab_at(s_r0[k * MP + m] + n);
+    const double v0 = e.y * s_t0[k * MP + m] + e.x;          // mfx_eval: separate multiply and add
+    if constexpr (BRACKET) {                                 // mfx_eval_br
+      const int r1 = s_r1[k * MP + m];
+      if (r1 < 0) return v0;
+      const double2 f = tab_at(r1 + n);
+      const double v1 = f.y * s_t1[k * MP + m] + f.x;
+      const double sl = (v1 - v0) / s_dG[m];
+      return sl * s_tG[m] + v0;
     }
+    return v0;
   };
 
   __syncthreads();   // s_Qx
@@ -163,33 +211,66 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                                 pos3(a11, ax[0], ax[cx], s_Gxx[0], s_Gxx[cx], s_Gxx[cx * MFX_XS + cx], y1, s_Yx[0], s_Yx[cx])));
     return r;
   };
+  MFX_STAMP(1);
   // ---- phase 1: column statistics + inner products with the extra columns (sequential over rows)
   double y_sq_seq = 0.0;
   for (int m = 0; m < M; ++m) y_sq_seq += s_y[m] * s_y[m];
   double umax = 0.0;
-  for (int col = tid; col < 2 * NP; col += WG) {
-    const int k = col >= NP, n = col - k * NP;
-    double a2 = 0.0, ay = 0.0, ax[MFX_XS];
+  // The inner products of the rotated atoms with the extra columns and the signal are a dense product
+  // [x_0 .. x_{NX-1} | y]^T D (at most 16 rows: one MFMA row tile) - on FP64 MFMA, 16 atoms at a time, a wave taking
+  // every NW-th atom tile of the two dictionaries and reading its B operand (the 16 rotated atoms) straight from the
+  // table into registers; |d|^2 comes from the same fragments.  (Thread-per-atom sequential sums took 0.4-1.8 M
+  // cycles per voxel here: LDS instruction issue for the extra columns, 64-bit addressing.)  These sums only rank and
+  // set thresholds - their order differs from the reference's - every reported number is re-summed in the exact stage.
+  {
+    double afx[KSTEPS];
 #pragma unroll
-    for (int e = 0; e < MFX_XS; ++e) ax[e] = 0.0;
-    if (n < N) {
-      for (int m = 0; m < M; ++m) {
-        const double d = elem(k, m, n);
-        a2 += d * d;
-        ay += s_y[m] * d;
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const int m = 4 * kk + lg;
+      afx[kk] = (m < M) ? (lc < NX ? xx[(size_t)m * NX + lc] : (lc == NX ? s_y[m] : 0.0)) : 0.0;
+    }
+    for (int tile = wave; tile < 2 * ntiles; tile += NW) {
+      const int k = tile >= ntiles, n0t = (tile - k * ntiles) * 16;
+      const int n = n0t + lc;
+      double bfr[KSTEPS];
 #pragma unroll
-        for (int e = 0; e < MFX_XS; ++e)
-          if (e < NX) ax[e] += d * xx[(size_t)m * NX + e];
+      for (int kk = 0; kk < KSTEPS; ++kk) bfr[kk] = (n < N) ? elem(k, 4 * kk + lg, n) : 0.0;   // rows beyond M: the zero table row
+      d4x c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+      double a2 = 0.0;
+      mfx_static_for<0, KSTEPS>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        if constexpr (kk % 2 == 0) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afx[kk], bfr[kk], c0, 0, 0, 0);
+        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afx[kk], bfr[kk], c1, 0, 0, 0);
+        a2 = fma(bfr[kk], bfr[kk], a2);
+      });
+      a2 += __shfl_xor(a2, 16);
+      a2 += __shfl_xor(a2, 32);
+      // lane (lg, lc): rows lg, lg+4, lg+8, lg+12 of column lc = inner products of atom n with extra columns e = lg + 4r
+      double* axp = wsA + ((size_t)k * NP + n) * MFX_XS;
+      double ayv = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = lg + 4 * r;
+        const double v = c0[r] + c1[r];
+        axp[e] = (e < NX) ? v : 0.0;
+        if (e == NX) ayv = v;
+      }
+      // the y row sits in lane group NX & 3: bring d.y to every lane of the column
+      ayv = __shfl(ayv, ((NX & 3) << 4) | lc);
+      if (lg == 0) {
+        (k ? s_A22 : s_A11)[n] = (n < N) ? a2 : 0.0;
+        (k ? s_Y2 : s_Y1)[n] = (n < N) ? ayv : 0.0;
       }
     }
-    (k ? s_A22 : s_A11)[n] = a2;
-    (k ? s_Y2 : s_Y1)[n] = ay;
-    double* axp = wsA + ((size_t)k * NP + n) * MFX_XS;
-#pragma unroll
-    for (int e = 0; e < MFX_XS; ++e) axp[e] = ax[e];
-    // (scored from the slab, not from ax[]: a dynamically indexed register array would live in scratch)
-    if (n < N)
-      for (int t = 0; t < ntup; ++t) umax = fmax(umax, atom_best(a2, ay, axp, t));
+    __syncthreads();   // statistics and slab complete (workgroup scope)
+    for (int col = tid; col < 2 * NP; col += WG) {
+      const int k = col >= NP, n = col - k * NP;
+      if (n < N) {
+        const double* axp = wsA + (size_t)col * MFX_XS;
+        const double a2v = (k ? s_A22 : s_A11)[n], ayv = (k ? s_Y2 : s_Y1)[n];
+        for (int t = 0; t < ntup; ++t) umax = fmax(umax, atom_best(a2v, ayv, axp, t));
+      }
+    }
   }
   for (int t = 0; t < ntup; ++t) umax = fmax(umax, s_Qx[t]);
 #pragma unroll
@@ -201,21 +282,111 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double gmax_run = s_red[0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) gmax_run = fmax(gmax_run, s_red[w]);
+  if (tid == 0) s_thr[0] = (unsigned long long)__double_as_longlong(gmax_run > 0.0 ? gmax_run : 0.0);
   __syncthreads();   // s_red is reused by the rounds
+  // ---- filter constants.  Once per voxel: the threshold-independent part of every (atom, tuple) -> slab wsP
+  for (int q = tid; q < 2 * NP * (ntup + 1); q += WG) {
+    const int kn = q / (ntup + 1), t = q - kn * (ntup + 1);
+    const int k = kn >= NP, n = kn - k * NP;
+    ProjB pb;
+    pb.u = 0.0; pb.np = 0.0f; pb.zp = 0.0f;
+    if (n < N) {
+      const double a2 = (k ? s_A22 : s_A11)[n], ay = (k ? s_Y2 : s_Y1)[n];
+      const double* axp = wsA + (size_t)kn * MFX_XS;
+      const double uf = HASF ? axp[0] * s_tc[4 * MFX_XS] : 0.0;
+      if (t == ntup) {
+        pb.u = uf;
+      } else {
+        const int cx = x0 + t;
+        const double ut = (axp[cx] - uf * s_tc[4 * t]) * s_tc[4 * t + 1];
+        const double n2 = a2 - uf * uf - ut * ut;                            // |d'|^2
+        const double zn = ay - uf * s_tc[4 * MFX_XS + 1] - ut * s_tc[4 * t + 2];   // d' . y'
+        pb.u = ut;
+        if (n2 > 1e-10 * a2) {
+          const double np = sqrt(n2);
+          pb.np = (float)np;
+          pb.zp = (float)(zn / np);
+        }
+      }
+    }
+    wsP[q] = pb;
+  }
+  __syncthreads();   // (workgroup-scope visibility of the slab, as for wsA)
+  // for a threshold T: (P + D) |d'|, (1 - D) Q |d'| in FP32, P rounded up, Q down (only lets more pairs through)
+  auto proj_c = [&](const ProjB& pb, int t, double T) -> ProjC {
+    ProjC c;
+    c.u = pb.u;
+    const float Tp = (float)(T - s_tc[4 * t + 3]) * (1.0f - 2e-7f);   // what the two projected atoms must reach (rounded down)
+    const float z = pb.zp;
+    const bool always = !(pb.np > 0.0f) || !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 1e-6f));
+    const float rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 4e-7f);
+    const float P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
+    const float Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
+    c.pn = always ? 1e18f : (P + MFX_XD) * pb.np * (1.0f + 2e-7f);
+    c.qn = always ? 0.0f : Q * ((1.0f - MFX_XD) * pb.np) * (1.0f - 2e-7f);
+    return c;
+  };
 
-  auto gen_chunk = [&](int ch, int buf) {
-    const int c = tid & 15, m0 = tid >> 4;  // WG/16 row groups
+  // generation of one 16-atom chunk of D2: the table entries are LOADED before the MFMAs of the current chunk and turned
+  // into LDS entries after them (the loads fly behind the matrix work instead of in front of it)
+  constexpr int NEL = (MP * 16 + WG - 1) / WG;   // elements per thread
+  double2 ge0[NEL], ge1[BRACKET ? NEL : 1];
+  ProjB gpb;
+  gpb.u = 0.0; gpb.np = 0.0f; gpb.zp = 0.0f;
+  double ga2x = 0.0;
+  auto gen_load = [&](int ch) {
+    if (tid < 16 * MFX_XS) ga2x = wsA[((size_t)NP + ch * 16) * MFX_XS + tid];   // A2x of the chunk's 16 atoms
+    const int c = tid & 15, m0 = tid >> 4;
     const int n = ch * 16 + c;
-    double* dst = sB + (size_t)buf * (MP * 16) + c;
-    for (int m = m0; m < MP; m += WG / 16) dst[m * 16] = elem(1, m, n);
-    if (tid < 16 * MFX_XS) {  // stage A2x of the chunk's 16 atoms
-      const int cc = tid / MFX_XS, e = tid - cc * MFX_XS;
-      s_a2x[(buf * 16 + cc) * MFX_XS + e] = wsA[((size_t)NP + ch * 16 + cc) * MFX_XS + e];
+    if (tid >= WG - 16 * (ntup + 1)) {   // filter base values of the chunk's columns: (column, tuple) and (column, fixed)
+      const int q = tid - (WG - 16 * (ntup + 1));
+      gpb = wsP[((size_t)NP + ch * 16) * (ntup + 1) + q];
+    }
+#pragma unroll
+    for (int p = 0; p < NEL; ++p) {
+      const int m = min(m0 + p * (WG / 16), MP - 1);
+      ge0[p] = tab_at(s_r0[MP + m] + n);
+      if constexpr (BRACKET) {
+        const int r1 = s_r1[MP + m];
+        ge1[p] = tab_at((r1 < 0 ? a.T.P * ldn : r1) + n);
+      }
     }
   };
+  auto gen_store = [&](int ch, int buf) {
+    const int c = tid & 15, m0 = tid >> 4;
+    double* dst = sB + (size_t)buf * (MP * 16) + c;
+#pragma unroll
+    for (int p = 0; p < NEL; ++p) {
+      const int m = m0 + p * (WG / 16);
+      if (m < MP) {
+        double v = ge0[p].y * s_t0[MP + m] + ge0[p].x;       // mfx_eval: separate multiply and add
+        if constexpr (BRACKET) {
+          if (s_r1[MP + m] >= 0) {                           // mfx_eval_br
+            const double v1 = ge1[p].y * s_t1[MP + m] + ge1[p].x;
+            const double sl = (v1 - v) / s_dG[m];
+            v = sl * s_tG[m] + v;
+          }
+        }
+        dst[m * 16] = v;
+      }
+    }
+    if (tid < 16 * MFX_XS) s_a2x[buf * 16 * MFX_XS + tid] = ga2x;
+    if (tid >= WG - 16 * (ntup + 1)) {   // filter constants of the chunk's columns for the current threshold
+      const int q = tid - (WG - 16 * (ntup + 1));
+      const int cc = q / (ntup + 1), t = q - cc * (ntup + 1);
+      if (t == ntup) {
+        s_colf[buf * 16 + cc] = gpb.u;
+      } else {
+        const double T = __longlong_as_double((long long)s_thr[0]) - eps_abs_of * y_sq;
+        s_colc[(buf * 16 + cc) * ntup + t] = proj_c(gpb, t, T);
+      }
+    }
+  };
+  auto gen_chunk = [&](int ch, int buf) { gen_load(ch); gen_store(ch, buf); };
 
   const int nrounds = (ntiles + NW - 1) / NW;
   const double eps_abs = eps_abs_of * y_sq;
+  MFX_STAMP(2);
 
   for (int round = 0; round < nrounds; ++round) {
     const int rt = round * NW + wave;
@@ -231,22 +402,70 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     int bj[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bs2[r] = 0.0; bj[r] = -1; }
+    // filter constants of this wave's 16 rows for the threshold thr_rows (refreshed when the threshold has risen)
+    double thr_rows = -1.0;
+    auto row_consts = [&](double T) {
+      thr_rows = T;
+      for (int q = lane; q < 16 * (ntup + 1); q += 64) {
+        const int il = q / (ntup + 1), t = q - il * (ntup + 1);
+        ProjB pb;
+        pb.u = 0.0; pb.np = 0.0f; pb.zp = 0.0f;
+        if (rt_valid) pb = wsP[((size_t)rt * 16) * (ntup + 1) + q];   // (atoms beyond N: np = 0, they pass and are skipped by the scan)
+        if (t == ntup) s_rowf[wave * 16 + il] = pb.u;
+        else s_rowc[(wave * 16 + il) * ntup + t] = proj_c(pb, t, T);
+      }
+      __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations execute in order: its later reads see these writes)
+    };
 
+    if (round == 0) MFX_STAMP(3);
     gen_chunk(0, 0);
     __syncthreads();
+    if (round == 0) MFX_STAMP(4);
     for (int ch = 0; ch < ntiles; ++ch) {
       const int buf = (NBUF == 2) ? (ch & 1) : 0;
+      {
+        const double T = __longlong_as_double((long long)s_thr[0]) - eps_abs;
+        if (T > thr_rows && (ch & 3) == 0) row_consts(T);
+      }
+#ifdef MFX_STAMPS_W   // diagnostic: where a chunk's time goes (chunk 10 of round 1; waves 0 and 7), tools/dev_stamps_k2x.py w
+#define MFX_XSTAMP(k) do { if (a.stamps && round == 1 && ch == 10 && (tid == 0 || tid == WG - 64)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFX_XSTAMP(k) do { } while (0)
+#endif
+      MFX_XSTAMP(0);
       if constexpr (NBUF == 2) {
-        if (ch + 1 < ntiles) gen_chunk(ch + 1, buf ^ 1);
+        if (ch + 1 < ntiles) gen_load(ch + 1);
       } else if (ch > 0) {
         gen_chunk(ch, 0);
         __syncthreads();
       }
+      MFX_XSTAMP(1);
+      d4x acc = {0, 0, 0, 0};
       if (rt_valid) {
+        // B operands read PD k-steps ahead into their own registers (a read right in front of its MFMA leaves the
+        // matrix pipe idle for an LDS round trip per k-step), two accumulator chains (a dependent FP64 MFMA chain
+        // issues every 72 cycles instead of 64); the sum of the chains is ranking-grade like everything in the scan
         const double* bp = sB + (size_t)buf * (MP * 16) + lg * 16 + lc;
-        d4x acc = {0, 0, 0, 0};
+        constexpr int PD = 4;
+        double bb[PD + 1];
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bp[kk * 64], acc, 0, 0, 0);
+        for (int q = 0; q < PD; ++q) bb[q] = bp[q * 64];
+        d4x acc1 = {0, 0, 0, 0};
+        mfx_static_for<0, KSTEPS>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value;
+          if constexpr (kk + PD < KSTEPS) bb[(kk + PD) % (PD + 1)] = bp[(kk + PD) * 64];
+          if constexpr (kk % 2 == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb[kk % (PD + 1)], acc, 0, 0, 0);
+          else acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], bb[kk % (PD + 1)], acc1, 0, 0, 0);
+        });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+      }
+      MFX_XSTAMP(2);
+      if constexpr (NBUF == 2) {
+        if (ch + 1 < ntiles) gen_store(ch + 1, buf ^ 1);   // nobody reads that buffer during this chunk; the loads have landed
+      }
+      MFX_XSTAMP(3);
+      if (rt_valid) {
         const int j = ch * 16 + lc;
         if (j < N) {
           // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports whose
@@ -255,11 +474,43 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
           // eliminated once (LDL^T), per extra column only the last row is added.
           const double a22 = s_A22[j], y2 = s_Y2[j];
           const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
+          // ---- filter: which tuples of the lane's four pairs can reach the threshold at all (see the top of the file)
+          float bmax[4] = {-1.0f, -1.0f, -1.0f, -1.0f};   // >= 0: some tuple of the pair passes
+          double accf[4];
+          const ProjC* cc = s_colc + (buf * 16 + lc) * ntup;
+          const ProjC* rc = s_rowc + (wave * 16 + lg) * ntup;
+          {
+            const double uf2 = s_colf[buf * 16 + lc];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accf[r] = HASF ? fma(-s_rowf[wave * 16 + lg + 4 * r], uf2, acc[r]) : acc[r];
+            const ProjC* r0p = rc, *r1p = rc + 4 * ntup, *r2p = rc + 8 * ntup, *r3p = rc + 12 * ntup;
+            for (int t = 0; t < ntup; ++t) {
+              const ProjC c2 = cc[t];
+              const ProjC c10 = r0p[t], c11 = r1p[t], c12 = r2p[t], c13 = r3p[t];
+              bmax[0] = fmaxf(bmax[0], fmaf(-c10.qn, c2.qn, fmaf(c10.pn, c2.pn, -(float)fma(-c10.u, c2.u, accf[0]))));
+              bmax[1] = fmaxf(bmax[1], fmaf(-c11.qn, c2.qn, fmaf(c11.pn, c2.pn, -(float)fma(-c11.u, c2.u, accf[1]))));
+              bmax[2] = fmaxf(bmax[2], fmaf(-c12.qn, c2.qn, fmaf(c12.pn, c2.pn, -(float)fma(-c12.u, c2.u, accf[2]))));
+              bmax[3] = fmaxf(bmax[3], fmaf(-c13.qn, c2.qn, fmaf(c13.pn, c2.pn, -(float)fma(-c13.u, c2.u, accf[3]))));
+            }
+          }
+          unsigned pass[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pass[r] = bmax[r] >= 0.0f ? 1u : 0u;
+#ifdef MFX_STAMPS
+          if (a.stamps) {   // diagnostics: tuples that pass the filter / (wave, row group) scoring passes executed
+            const int np_ = (int)(pass[0] + pass[1] + pass[2] + pass[3]);   // pairs with a passing tuple
+            if (np_) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)np_);
+            for (int r = 0; r < 4; ++r) {
+              const unsigned long long bal = __ballot(pass[r] != 0);
+              if (bal && lane == __ffsll((long long)bal) - 1) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], 1ull);
+            }
+          }
+#endif
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int il = lg + 4 * r;
             const int i = rt * 16 + il;
-            if (i < N) {
+            if (i < N && pass[r]) {
               const double a11 = s_A11[i], y1 = s_Y1[i], a12 = acc[r];
               const double* a1x = s_a1x + (wave * 16 + il) * MFX_XS;
               // LDL^T of the {1,2} block
@@ -292,6 +543,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                 s = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(s, S3u) : s;  // {1,2,f}
               }
               for (int t = 0; t < ntup; ++t) {
+                {   // the filter again, for this tuple alone (the pass above only kept "some tuple passes")
+                  const ProjC c2 = cc[t], c1 = rc[4 * r * ntup + t];
+                  if (!(fmaf(-c1.qn, c2.qn, fmaf(c1.pn, c2.pn, -(float)fma(-c1.u, c2.u, accf[r]))) >= 0.0f)) continue;
+                }
                 const int cx = x0 + t;
                 const double a1e = a1x[cx], a2e = a2x[cx], aee = s_Gxx[cx * MFX_XS + cx], ye = s_Yx[cx];
                 // support {1,2,x}: last row of the LDL^T on top of the {1,2} block
@@ -321,6 +576,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                   s = (ok4 && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0 && w4 >= 0.0) ? fmax(s, fma(u4, w4, S3u)) : s;
                 }
               }
+              // a better score raises the workgroup's threshold (the filter constants follow at their next refresh)
+              if (s > __longlong_as_double((long long)s_thr[0])) atomicMax(&s_thr[0], (unsigned long long)__double_as_longlong(s));
               // slot update: columns come in increasing j, strict '>' keeps the first of equal scores
               const bool better = s > bs[r];
               bs2[r] = better ? bs[r] : fmax(bs2[r], s);
@@ -330,8 +587,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
           }
         }
       }
+      MFX_XSTAMP(4);
       __syncthreads();
+      MFX_XSTAMP(5);
     }
+    if (round == 0) MFX_STAMP(5);
     double lmax = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) lmax = fmax(lmax, bs[r]);
@@ -363,6 +623,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     __syncthreads();
   }
 
+  MFX_STAMP(6);
   // ---- one-atom and no-atom supports within rounding distance of the optimum -> family items
   const double thr_final = gmax_run - eps_abs;
   for (int col = tid; col < 2 * NP; col += WG) {
@@ -383,6 +644,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   }
   __syncthreads();
 
+  MFX_STAMP(7);
   // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
   const int nappend = s_cnt[0], nfam_app = s_cnt[1];
   const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
@@ -496,6 +758,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     ((long*)s_win)[5] = bk;
   }
   __syncthreads();
+  MFX_STAMP(8);
   if (wave == 0) {
     const double best = s_win[0];
     const double w0 = s_win[1], w1 = s_win[2], w2 = s_win[3], w3 = s_win[4];
@@ -550,4 +813,5 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       out[a.num_params - 1] = r2;
     }
   }
+  MFX_STAMP(9);
 }
