@@ -68,7 +68,9 @@ int mfx_tables_num_atoms(const mfx_tables* t);
  * multishell: mf_utils.py:1810-1839 (exact float equality of G, else bracketing pair,
  * MFX_ERR_G_RANGE outside the table range).  scheme [M x 7] = [gx gy gz G Delta delta TE].
  * explicit: rotate_atom (mf_utils.py:1205-1437): the caller has already grouped rows
- * into (G,Delta,delta) shells; gdirs [M x 3] are used as given, shell_of_row [M].   */
+ * into (G,Delta,delta) shells; gdirs [M x 3] are used as given, shell_of_row [M].  With such a
+ * plan every fascicle direction is divided by its norm before use, in mfx_rotate* and in the
+ * voxel loop alike (rotate_atom normalises newdir, mf_utils.py:1262-1270, and has no unit-norm check). */
 int mfx_plan_create_multishell(const mfx_tables* t, const double* scheme, int M, mfx_plan** out);
 int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs, const int32_t* shell_of_row, int M,
                              mfx_plan** out);
@@ -95,7 +97,9 @@ int mfx_rotate_cols_dev(const mfx_plan* p, const double* d_dirs, const int32_t* 
 /* ---- the voxel loop: replaces MFModel.fit's loop over _fit_voxel
  * (mf.py:976-1032 calling mf.py:340-461).
  * Y       [V x M]           measured signals (ROI order)
- * K       [V]               number of fascicles per voxel (0..maxfasc), maxfasc <= 2
+ * K       [V]               number of fascicles per voxel (0..maxfasc), maxfasc <= 3 (MFModel.fit stops at 2, mf.py:467;
+ *                           three fascicles - BASELINE config 5 - are opt-in here and run voxel by voxel through the
+ *                           explicit-dictionary solver: reference solve_exhaustive_posweights_3 / _4up arithmetic)
  * csf,ear [V] or NULL       per-voxel compartment flags
  * peaks   [V x 3*maxfasc]   fascicle directions (unit norm +-1e-3, checked once per batch)
  * sig_csf [M] / sig_ear [M x E]  (NULL when csf_on / ear_on is 0)

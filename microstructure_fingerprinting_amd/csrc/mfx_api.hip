@@ -246,7 +246,7 @@ extern "C" int mfx_tables_num_atoms(const mfx_tables* t) { return t ? t->d.N : 0
 
 static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g, const std::vector<int>& slo,
                        const std::vector<int>& shi, const std::vector<double>& tG, const std::vector<double>& dG,
-                       mfx_plan** out) {
+                       int normalise, mfx_plan** out) {
   std::unique_ptr<mfx_plan> p(new mfx_plan());
   p->t = t;
   HIPCHK(hipSetDevice(t->device));
@@ -270,6 +270,7 @@ static int plan_upload(const mfx_tables* t, int M, const std::vector<double>& g,
   p->d.tG = (const double*)p->dtG;
   p->d.dG = (const double*)p->ddG;
   p->d.any_bracket = 0;
+  p->d.normalise = normalise;
   for (int m = 0; m < M; ++m) p->d.any_bracket |= (shi[m] >= 0);
   // ---- screening view
   p->d.tab32s = t->d.tab32; p->d.xs = nullptr; p->d.offs = nullptr; p->d.s_scr = nullptr;
@@ -375,7 +376,7 @@ extern "C" int mfx_plan_create_multishell(const mfx_tables* t, const double* sch
     tG[m] = G - t->h_G[ih - 1];
     dG[m] = t->h_G[ih] - t->h_G[ih - 1];
   }
-  return plan_upload(t, M, g, slo, shi, tG, dG, out);
+  return plan_upload(t, M, g, slo, shi, tG, dG, 0, out);
 }
 
 extern "C" int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs, const int32_t* shell_of_row, int M,
@@ -387,7 +388,8 @@ extern "C" int mfx_plan_create_explicit(const mfx_tables* t, const double* gdirs
     if (shell_of_row[m] < 0 || shell_of_row[m] >= t->d.S) return fail(MFX_ERR_ARG, "row %d: shell %d out of range", m, shell_of_row[m]);
     slo[m] = shell_of_row[m];
   }
-  return plan_upload(t, M, g, slo, shi, tG, dG, out);
+  // rotate_atom semantics: the fit kernels divide every fascicle direction by its norm first (mf_utils.py:1262-1270)
+  return plan_upload(t, M, g, slo, shi, tG, dG, 1, out);
 }
 
 extern "C" void mfx_plan_destroy(mfx_plan* p) {
@@ -513,9 +515,14 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
 }
 
 // one homogeneous voxel class (every voxel: K fascicles, has_csf, has_ear); device pointers
+static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list,
+                             int nvox, int K, const ExtrasHost& X, int maxfasc, int csf_on, int ear_on, double* d_params,
+                             hipStream_t st);
+
+// h_list: host copy of d_list (null with d_list == null: the identity)
 static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
-                         int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc, int csf_on,
-                         int ear_on, double* d_params, hipStream_t st) {
+                         const int* h_list, int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc,
+                         int csf_on, int ear_on, double* d_params, hipStream_t st) {
   const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   if (nvox == 0) return MFX_OK;
   if (K + has_csf + has_ear == 0) return MFX_OK;  // mf.py:387-388: rows stay zero
@@ -541,14 +548,75 @@ static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_p
     a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc; a.csf_on = csf_on; a.ear_on = ear_on;
     return mfx_launch_k2x(a, nvox, st);
   }
+  if (K == 3) return fit_class_generic(p, d_Y, d_peaks, peaks_ld, h_list, nvox, K, X, maxfasc, csf_on, ear_on, d_params, st);
   return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented", K, has_csf, has_ear);
+}
+
+// Three fascicles (BASELINE config 5; opt-in, MFModel.fit itself stops at two): no fused kernel yet - voxel after voxel
+// the rotated dictionaries are materialised into one row-major [M x (K N + extras)] matrix on the device and go through
+// the explicit-dictionary solver (solve_generic.hip: Gram, one thread per index tuple, exact finalize in the
+// reference's _3 / _4up arithmetic and scan order), then the params row is packed.  Everything is enqueued on `st`.
+static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list,
+                             int nvox, int K, const ExtrasHost& X, int maxfasc, int csf_on, int ear_on, double* d_params,
+                             hipStream_t st) {
+  const int M = p->d.M, N = p->t->d.N, NX = X.d.NX, E = X.d.E, has_csf = X.d.has_csf;
+  const int Kp = K + has_csf + (E > 0);
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  if (Kp > MFX_GK) return fail(MFX_ERR_UNSUPPORTED, "at most %d sub-dictionaries", MFX_GK);
+  SolveArgs a{};
+  long Ntot = 0, ntup = 1;
+  for (int k = 0; k < Kp; ++k) {
+    const long sz = k < K ? N : ((has_csf && k == K) ? 1 : E);
+    a.sizes[k] = sz; a.start[k] = Ntot; Ntot += sz;
+    if (ntup > (1L << 42) / sz) return fail(MFX_ERR_UNSUPPORTED, "too many index tuples per voxel for the generic three-fascicle path");
+    ntup *= sz;
+  }
+  a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
+  a.nblocks = (int)std::min<long>(16384, (ntup + 255) / 256);
+  StreamMem dA(st), dG(st), dAty(st), dysq(st), dbs(st), dbt(st), dw(st), dsub(st), dobj(st), dyrec(st);
+  HIPCHK(dA.alloc(sizeof(double) * (size_t)M * Ntot));
+  HIPCHK(dG.alloc(sizeof(double) * (size_t)Ntot * Ntot));
+  HIPCHK(dAty.alloc(sizeof(double) * Ntot));
+  HIPCHK(dysq.alloc(sizeof(double) * 2));
+  HIPCHK(dbs.alloc(sizeof(double) * a.nblocks));
+  HIPCHK(dbt.alloc(sizeof(long) * a.nblocks));
+  HIPCHK(dw.alloc(sizeof(double) * MFX_GK));
+  HIPCHK(dsub.alloc(sizeof(long) * MFX_GK));
+  HIPCHK(dobj.alloc(sizeof(double)));
+  HIPCHK(dyrec.alloc(sizeof(double) * M));
+  a.A = dA.as<double>(); a.G = dG.as<double>(); a.Aty = dAty.as<double>(); a.ysq = dysq.as<double>();
+  a.blk_score = dbs.as<double>(); a.blk_tuple = dbt.as<long>(); a.w = dw.as<double>(); a.sub = dsub.as<long>();
+  a.minobj = dobj.as<double>(); a.yrec = dyrec.as<double>();
+  // the voxel-independent extra columns sit behind the fascicle blocks (sub-dictionary order of mf.py:391-408)
+  if (NX > 0)
+    HIPCHK(hipMemcpy2DAsync(dA.as<double>() + (size_t)K * N, sizeof(double) * Ntot, X.d.x, sizeof(double) * NX, sizeof(double) * NX, M,
+                            hipMemcpyDeviceToDevice, st));
+  if (int rc = mfx_prof_begin(st)) return rc;
+  for (int q = 0; q < nvox; ++q) {
+    const long v = h_list ? h_list[q] : q;
+    dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, K);
+    hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, st, p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
+                       dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
+    a.y = d_Y + (size_t)v * M;
+    const long work = Ntot * Ntot + Ntot + 2;
+    hipLaunchKernelGGL(mfx_gram_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, st, a);
+    PackArgs pa{};
+    pa.w = a.w; pa.sub = a.sub; pa.minobj = a.minobj; pa.yrec = a.yrec; pa.y = a.y;
+    pa.M = M; pa.K = K; pa.has_csf = has_csf; pa.E = E; pa.maxfasc = maxfasc; pa.csf_on = csf_on; pa.ear_on = ear_on;
+    pa.num_params = num_params; pa.out = d_params + (size_t)v * num_params;
+    hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, st, pa);
+  }
+  HIPCHK(hipGetLastError());
+  return mfx_prof_end(st);
 }
 
 extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int maxfasc, int csf_on,
                                  int ear_on, const double* d_sig_csf, const double* d_sig_ear, int E, int64_t V,
                                  double* d_params_out, void* stream) {
   if (!p || !d_Y || !d_params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: bad argument");
-  if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (maxfasc < 0 || maxfasc > 3) return fail(MFX_ERR_ARG, "maxfasc must be 0..3 (MFModel.fit itself allows 2: MAX_FASC, mf.py:467)");
   if (maxfasc > 0 && !d_peaks) return fail(MFX_ERR_ARG, "mfx_fit_batch_dev: d_peaks is null but maxfasc = %d", maxfasc);
   if (V == 0) return MFX_OK;
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
@@ -557,7 +625,7 @@ extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const dou
   if (int rc = mfx_fb_begin(st)) return rc;
   ExtrasHost X;
   if (int rc = X.build(p->d.M, csf_on ? 1 : 0, ear_on ? E : 0, d_sig_csf, d_sig_ear, st)) return rc;
-  if (int rc = fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
+  if (int rc = fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
                              csf_on ? 1 : 0, ear_on ? 1 : 0, d_params_out, st)) return rc;
   return mfx_fb_end(st);
 }
@@ -593,7 +661,7 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
                                   int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
                                   double* params_out) {
   if (!p || !Y || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
-  if (maxfasc < 0 || maxfasc > 2) return fail(MFX_ERR_ARG, "maxfasc must be 0..2 (MFModel.MAX_FASC, mf.py:467)");
+  if (maxfasc < 0 || maxfasc > 3) return fail(MFX_ERR_ARG, "maxfasc must be 0..3 (MFModel.fit itself allows 2: MAX_FASC, mf.py:467)");
   if (maxfasc > 0 && !peaks) return fail(MFX_ERR_ARG, "mfx_fit_batch: peaks is null but maxfasc = %d", maxfasc);
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large");
   if (int rc = require_device(p->t->device)) return rc;
@@ -607,7 +675,7 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, ((int64_t)32 << 20) / ((int64_t)M * 8)));
   const int64_t nch = (V + CH - 1) / CH;
   std::vector<int> list((size_t)V);              // voxel lists, chunk-major then class-major
-  std::vector<int> cnt((size_t)nch * 12, 0);
+  std::vector<int> cnt((size_t)nch * 16, 0);
   {
     std::vector<uint8_t> cls((size_t)V);
     for (int64_t v = 0; v < V; ++v) {
@@ -615,19 +683,19 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
       if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
       const int c = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
       if ((c && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
-      for (int f = 0; f < k; ++f) {
+      for (int f = 0; f < k && !p->d.normalise; ++f) {   // (explicit rotate_atom plans normalise the direction themselves)
         const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
         const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         if (!(std::fabs(1 - nrm) <= 1e-3))
           return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
       }
       cls[(size_t)v] = (uint8_t)(k * 4 + c * 2 + e);
-      ++cnt[(size_t)(v / CH) * 12 + cls[(size_t)v]];
+      ++cnt[(size_t)(v / CH) * 16 + cls[(size_t)v]];
     }
-    std::vector<size_t> pos((size_t)nch * 12);
+    std::vector<size_t> pos((size_t)nch * 16);
     size_t acc = 0;
     for (size_t q = 0; q < pos.size(); ++q) { pos[q] = acc; acc += (size_t)cnt[q]; }
-    for (int64_t v = 0; v < V; ++v) list[pos[(size_t)(v / CH) * 12 + cls[(size_t)v]]++] = (int)v;
+    for (int64_t v = 0; v < V; ++v) list[pos[(size_t)(v / CH) * 16 + cls[(size_t)v]]++] = (int)v;
   }
   if (int rc = pipe_setup(p->t->device, (size_t)CH * M * sizeof(double))) return rc;
   MfxThread& T = mfx_thread();
@@ -670,11 +738,11 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
       HIPCHK(hipMemcpyAsync(dY.as<double>() + (size_t)v0 * M, stg, sizeof(double) * (size_t)nv * M, hipMemcpyHostToDevice, T.s_copy));
       HIPCHK(hipEventRecord(T.ev_h2d[c & 1], T.s_copy));
       HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[c & 1], 0));
-      for (int q = 0; q < 12; ++q) {
-        const int n = cnt[(size_t)c * 12 + q];
+      for (int q = 0; q < 16; ++q) {
+        const int n = cnt[(size_t)c * 16 + q];
         if (!n) continue;
-        if (int rc = fit_class_dev(p, dY.as<double>(), dpk.as<double>(), 3 * maxfasc, dlist.as<int>() + off, n, q >> 2, (q >> 1) & 1,
-                                   q & 1, xs[q & 3], maxfasc, csf_on, ear_on, dpar.as<double>(), T.s_comp)) return rc;
+        if (int rc = fit_class_dev(p, dY.as<double>(), dpk.as<double>(), 3 * maxfasc, dlist.as<int>() + off, list.data() + off, n, q >> 2,
+                                   (q >> 1) & 1, q & 1, xs[q & 3], maxfasc, csf_on, ear_on, dpar.as<double>(), T.s_comp)) return rc;
         off += (size_t)n;
       }
     }
@@ -707,7 +775,7 @@ extern "C" int mfx_rotate_dev(const mfx_plan* p, const double* d_dirs, int64_t B
     const int nb = (int)std::min<int64_t>(32768, B - b0);
     dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, nb);
     hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, (hipStream_t)stream, p->t->d, p->d,
-                       d_dirs + 3 * b0, normalise_dirs, d_out + (size_t)b0 * M * p->t->d.N);
+                       d_dirs + 3 * b0, normalise_dirs, d_out + (size_t)b0 * M * p->t->d.N, (long)M * p->t->d.N, (long)p->t->d.N);
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;

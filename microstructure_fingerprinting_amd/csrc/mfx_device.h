@@ -31,6 +31,7 @@ struct PlanDev {
   const double* tG;  // [M]
   const double* dG;  // [M]
   int any_bracket;
+  int normalise;     // explicit (rotate_atom) plans: a fascicle direction is divided by its norm first (mf_utils.py:1262-1270)
   // Screening view of the protocol (fit_k2s.hip only ranks with it; exact arithmetic never uses it): every row maps
   // to ONE knot table.  Exact-shell rows use the table's own shells; a G-bracketed row uses a "virtual shell" built
   // once per plan: the blend (1-w) shell_lo + w shell_hi, w = (G-G_lo)/(G_hi-G_lo), which is itself piecewise linear
@@ -48,6 +49,7 @@ struct PlanDev {
 // the reference's per-voxel direction check (interp_PGSE_from_multishell, mf_utils.py:1798-1802), once per voxel and
 // fascicle: flags the plan's status word instead of raising (the device cannot), the voxel is still computed
 __device__ __forceinline__ void mfx_check_dir(const PlanDev& P, const double* __restrict__ pk, int vox) {
+  if (P.normalise) return;   // rotate_atom normalises the direction itself and has no such check
   const double nrm = sqrt((pk[0] * pk[0] + pk[1] * pk[1]) + pk[2] * pk[2]);
   if (!(fabs(1.0 - nrm) <= 1e-3) && P.status) {
     atomicOr(P.status, MFX_ST_DIR_NORM);
@@ -90,6 +92,10 @@ __device__ __forceinline__ double mfx_absdot(const double* __restrict__ g, doubl
 __device__ __forceinline__ RowDesc mfx_row_desc(const TablesDev& T, const PlanDev& P, int m, double d0, double d1,
                                                 double d2) {
   RowDesc rd;
+  if (P.normalise) {   // rotate_atom: newdir / |newdir| (mf_utils.py:1262, 1269)
+    const double nn = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+    d0 /= nn; d1 /= nn; d2 /= nn;
+  }
   const double u = mfx_absdot(P.g + 3 * m, d0, d1, d2);
   mfx_shell_locate(T, P.s_lo[m], u, rd.r0, rd.t0);
   rd.r1 = -1;

@@ -10,9 +10,11 @@
 #define MFX_ROT_ROWS 16
 #define MFX_ROT_WG 256
 
-// out[b][m][n], one workgroup per (direction b, block of MFX_ROT_ROWS protocol rows)
+// out[b * bstride + m * rstride + n] (b-major [B x M x N]: bstride = M N, rstride = N; sub-dictionary b of a row-major
+// [M x K N] matrix: bstride = N, rstride = K N), one workgroup per (direction b, block of MFX_ROT_ROWS protocol rows)
 __global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, PlanDev P, const double* __restrict__ dirs,
-                                                                int normalise, double* __restrict__ out) {
+                                                                int normalise, double* __restrict__ out, long bstride,
+                                                                long rstride) {
   __shared__ RowDesc s_rd[MFX_ROT_ROWS];
   __shared__ double s_tG[MFX_ROT_ROWS], s_dG[MFX_ROT_ROWS];
   const int b = blockIdx.y;
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, Pla
     const int m = m0 + threadIdx.x;
     if (m < M) {
       double d0 = dirs[3 * (size_t)b], d1 = dirs[3 * (size_t)b + 1], d2 = dirs[3 * (size_t)b + 2];
-      if (normalise) {  // rotate_atom: newdir / |newdir| (mf_utils.py:1262,1269)
+      if (normalise && !P.normalise) {  // rotate_atom: newdir / |newdir| (mf_utils.py:1262,1269); explicit plans do it in mfx_row_desc
         const double nn = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
         d0 /= nn; d1 /= nn; d2 /= nn;
       }
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, Pla
   const int rows = min(MFX_ROT_ROWS, M - m0);
   for (int idx = threadIdx.x; idx < rows * N; idx += MFX_ROT_WG) {
     const int r = idx / N, n = idx - r * N;
-    out[((size_t)b * M + m0 + r) * N + n] = mfx_eval_br(T.tab, ldn, s_rd[r], s_tG[r], s_dG[r], n);
+    out[(size_t)b * bstride + (size_t)(m0 + r) * rstride + n] = mfx_eval_br(T.tab, ldn, s_rd[r], s_tG[r], s_dG[r], n);
   }
 }
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void mfx_rotate_cols_kernel(TablesDev T, PlanD
   const int64_t b = idx / M;
   const int m = (int)(idx - b * M);
   double d0 = dirs[3 * b], d1 = dirs[3 * b + 1], d2 = dirs[3 * b + 2];
-  if (normalise) {
+  if (normalise && !P.normalise) {
     const double nn = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
     d0 /= nn; d1 /= nn; d2 /= nn;
   }

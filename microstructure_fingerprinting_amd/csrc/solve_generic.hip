@@ -297,3 +297,51 @@ __global__ __launch_bounds__(256) void mfx_tuple_finalize(SolveArgs a) {
     }
   }
 }
+
+
+// ---- params packing for the voxel loop's generic classes (mf.py:420-450) from the solver's outputs: one 64-thread workgroup
+struct PackArgs {
+  const double* w; const long* sub; const double* minobj; const double* yrec; const double* y;
+  int M, K, has_csf, E, maxfasc, csf_on, ear_on, num_params;
+  double* out;   // the voxel's params row
+};
+__global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) {
+  const int lane = threadIdx.x, M = a.M;
+  const int Kp = a.K + a.has_csf + (a.E > 0);
+  double sy = 0.0, sr = 0.0;
+  for (int m = lane; m < M; m += 64) { sy += a.y[m]; sr += a.yrec[m]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sy += __shfl_xor(sy, o); sr += __shfl_xor(sr, o); }
+  sy /= M; sr /= M;
+  double cyy = 0.0, crr = 0.0, cyr = 0.0;
+  for (int m = lane; m < M; m += 64) {
+    const double da = a.y[m] - sy, db = a.yrec[m] - sr;
+    cyy += da * da; crr += db * db; cyr += da * db;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cyy += __shfl_xor(cyy, o); crr += __shfl_xor(crr, o); cyr += __shfl_xor(cyr, o); }
+  double r2 = 0.0;
+  if (M > 1 && cyy > 0.0 && crr > 0.0) {
+    const double f = (double)(M - 1);
+    double r = (cyr / f) / sqrt(cyy / f) / sqrt(crr / f);
+    r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+    r2 = r * r;
+  }
+  if (lane == 0) {
+    double M0 = 0.0;
+    for (int k = 0; k < Kp; ++k) M0 += a.w[k];
+    for (int k = 0; k < a.K; ++k) {
+      a.out[1 + k] = (fabs(M0) > 0) ? a.w[k] / M0 : a.w[k];
+      a.out[1 + a.maxfasc + k] = (double)a.sub[k];
+    }
+    a.out[0] = M0;
+    const int i_csf = 2 * a.maxfasc + 1, i_ear = 2 * a.maxfasc + a.csf_on + 1;
+    if (a.has_csf) a.out[i_csf] = (fabs(M0) > 0) ? a.w[a.K] / M0 : a.w[a.K];
+    if (a.E > 0) {
+      a.out[i_ear] = (fabs(M0) > 0) ? a.w[a.K + a.has_csf] / M0 : a.w[a.K + a.has_csf];
+      a.out[i_ear + 1] = (double)a.sub[a.K + a.has_csf];
+    }
+    a.out[a.num_params - 2] = a.minobj[0] / M;
+    a.out[a.num_params - 1] = r2;
+  }
+}

@@ -464,3 +464,86 @@ def test_k2_long_protocols_wide_kernel_vs_fp64_kernel_and_oracle(N, dirs, bracke
     z = np.zeros(ns, bool)
     ref = orc.fit_batch(_tables(ms), sch, Y[sel], K[:ns], z, z, peaks[sel], 2, False, False, None, None, 0, nthreads=NTHREADS)
     _assert_rows(res[0][sel], ref, 2, "long protocol M=%d" % sch.shape[0])
+
+
+def test_three_fascicles_generic_class_vs_oracle():
+    """BASELINE config 5's class (three fascicles; opt-in on the C ABI, MFModel.fit stops at two like the reference):
+    sub-dictionaries [96, 96, 96] and [40, 40, 40, 1] against the oracle's solve_exhaustive_posweights_3 / _4up on
+    rotated dictionaries, incl. a voxel with two fascicles only."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    for N, c in ((96, 0), (40, 1)):
+        rng = np.random.default_rng(40 + N)
+        sch = synth.make_scheme(rng, 2, [1000, 2000, 3000], [30, 30, 30])
+        dic = synth.make_dictionary(rng, sch, N)
+        ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+        plan = ms.plan_for(sch)
+        T = _tables(ms)
+        V, M = 6, sch.shape[0]
+        peaks = np.concatenate([synth.unit_vectors(rng, V) for _ in range(3)], axis=1)
+        atoms = rng.integers(0, N, (V, 3))
+        nu = rng.dirichlet(np.ones(3 + c), V)
+        nu[1, 2] = 0.0
+        gam = mfu.get_gyromagnetic_ratio('H')
+        b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+        sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3.0e-9)
+        Y = rng.normal(0, 500.0 / 30.0, (V, M))
+        for k in range(3):
+            Y += 500.0 * nu[:, k:k + 1] * _rotate_cols(plan, peaks[:, 3 * k:3 * k + 3], atoms[:, k])
+        if c:
+            Y += 500.0 * nu[:, 3:4] * sig_csf
+        got = engine.fit_batch(plan, Y, np.full(V, 3), np.full(V, bool(c)), None, peaks, 3, bool(c), False, sig_csf if c else None)
+        for v in range(V):
+            A = np.concatenate([orc.interp(sch, peaks[v, 3 * k:3 * k + 3], T) for k in range(3)] + ([sig_csf[:, None]] if c else []), axis=1)
+            w, sub, tot, mo, yrec = orc.solve_exhaustive_posweights(np.ascontiguousarray(A), Y[v], np.array([N, N, N] + ([1] if c else [])))
+            act = w[:3] > 1e-9
+            assert np.array_equal(got[v, 4:7][act], sub[:3][act].astype(float)), (v, got[v], sub, w)
+            assert np.allclose(got[v, 0], w.sum(), rtol=1e-6) and np.allclose(got[v, 1:4], w[:3] / w.sum(), rtol=1e-6, atol=1e-9)
+            assert np.isclose(got[v, -2], mo / M, rtol=1e-6)
+
+
+def test_fit_over_rotate_atom_plan_vs_oracle():
+    """The voxel loop driven by rotate_atom tables (an explicit row plan: the dictionary is sampled on the subject's own
+    protocol, mf_utils.py:1205-1437 - the reference's test_hcp_dict shape of use) on the HCP-MGH fixture (552 rows x 782
+    atoms): two-fascicle voxels against orc.rotate_atom + the oracle's solve_exhaustive_posweights_2, and a
+    three-fascicle voxel on an atom subset against solve_exhaustive_posweights_3."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    d = np.load(os.path.join(G, "real_hcp.npz"))
+    sch, sig, S0, DIFF = np.ascontiguousarray(d["sch_mat"]), np.ascontiguousarray(d["dictionary"]), np.ascontiguousarray(d["S0"]), float(d["WM_DIFF"])
+    rng = np.random.default_rng(17)
+    N = sig.shape[1]
+    RT = mfu.RotateAtomTables(sig, sch, Z, DIFF, S0, warnings=False)
+    V = 12
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    peaks[:, :3] *= 1.0 + 1e-4 * rng.standard_normal((V, 1))        # rotate_atom normalises: any length is legal
+    atoms = rng.integers(0, N, (V, 2)); atoms[0] = 86
+    nu = rng.dirichlet(np.ones(2), V)
+    D = [RT.rotate(peaks[:, 3 * k:3 * k + 3]) for k in range(2)]       # [V, M, N] each
+    Y = rng.normal(0, 500.0 / 30.0, (V, sch.shape[0]))
+    for k in range(2):
+        Y += 500.0 * nu[:, k:k + 1] * np.take_along_axis(D[k], atoms[:, k][:, None, None], axis=2)[:, :, 0]
+    got = engine.fit_batch(RT.plan, Y, np.full(V, 2), None, None, peaks, 2, False, False)
+    for v in range(V):
+        A = np.concatenate([orc.rotate_atom(sig, sch, Z, peaks[v, 3 * k:3 * k + 3], DIFF, S0) for k in range(2)], axis=1)
+        w, sub, tot, mo, yrec = orc.solve_exhaustive_posweights(np.ascontiguousarray(A), Y[v], np.array([N, N]))
+        assert np.array_equal(got[v, 3:5], sub.astype(float)), (v, got[v], sub)
+        assert np.allclose(got[v, 1:3], w / w.sum(), rtol=1e-9) and np.isclose(got[v, 0], w.sum(), rtol=1e-9)
+    # three fascicles on 60 atoms of the same dictionary
+    sel = np.arange(0, N, 13)[:60]
+    RT3 = mfu.RotateAtomTables(np.ascontiguousarray(sig[:, sel]), sch, Z, DIFF, np.ascontiguousarray(S0[:, sel]), warnings=False)
+    pk3 = np.concatenate([synth.unit_vectors(rng, 2) for _ in range(3)], axis=1)
+    at3 = rng.integers(0, sel.size, (2, 3))
+    nu3 = rng.dirichlet(np.ones(3), 2)
+    Y3 = rng.normal(0, 500.0 / 30.0, (2, sch.shape[0]))
+    for k in range(3):
+        Dk = RT3.rotate(pk3[:, 3 * k:3 * k + 3])
+        Y3 += 500.0 * nu3[:, k:k + 1] * np.take_along_axis(Dk, at3[:, k][:, None, None], axis=2)[:, :, 0]
+    g3 = engine.fit_batch(RT3.plan, Y3, np.full(2, 3), None, None, pk3, 3, False, False)
+    for v in range(2):
+        A = np.concatenate([orc.rotate_atom(np.ascontiguousarray(sig[:, sel]), sch, Z, pk3[v, 3 * k:3 * k + 3], DIFF, np.ascontiguousarray(S0[:, sel])) for k in range(3)], axis=1)
+        w, sub, tot, mo, yrec = orc.solve_exhaustive_posweights(np.ascontiguousarray(A), Y3[v], np.array([sel.size] * 3))
+        assert np.array_equal(g3[v, 4:7], sub.astype(float)), (v, g3[v], sub)
+        assert np.allclose(g3[v, 1:4], w / w.sum(), rtol=1e-6, atol=1e-9)
