@@ -251,6 +251,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     glb_run = best1;
   }
   __syncthreads();
+  if (tid == 0) s_cnt[1] = s_cnt[0];   // the single-atom representatives appended so far (0..2); kept in LDS, not in a register
 
   // generation of one (16*TILES)-atom chunk of D2 into LDS buffer `buf`: thread -> (atom c, rows m0 + RS*p)
   constexpr int CW = 16 * TILES;  // atoms per chunk
@@ -554,9 +555,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
     double res = INFINITY, w0 = 0.0, w1 = 0.0;
     long idx = -1;
     if (nappend <= a.maxc) {
-      if (tid < ncand && s_cand[tid].score >= glb_run) {
-        exact_pair(s_cand[tid].i, s_cand[tid].j, w0, w1, res);
-        idx = (long)s_cand[tid].i * N + s_cand[tid].j;
+      // A scan candidate is the best pair of its (lane,row) slot - row i, the columns j = lc (mod 16).  A second pair
+      // of that slot within rounding distance of the optimum was never seen by the short list (one entry per slot):
+      // the whole slot row of every listed candidate is therefore evaluated exactly (<= N/16 pairs each; a slot that
+      // is not listed cannot hold a near-optimal pair: its best is below the threshold).  The first entries of the
+      // list are the single-atom representatives of phase 1: themselves only.
+      const int NJ = (N + 15) >> 4, nsingle = s_cnt[1];
+      for (int q = tid; q < ncand * NJ; q += WG) {
+        const int c = q / NJ, u = q - c * NJ;
+        if (!(s_cand[c].score >= glb_run)) continue;
+        const int ci = s_cand[c].i, cj = s_cand[c].j;
+        const int jj = (c < nsingle) ? cj : (cj & 15) + 16 * u;
+        if ((c < nsingle && u > 0) || jj >= N) continue;
+        double r, u0, u1;
+        exact_pair(ci, jj, u0, u1, r);
+        const long ix = (long)ci * N + jj;
+        if (r < res || (r == res && ix < idx)) { res = r; idx = ix; w0 = u0; w1 = u1; }
       }
     } else {
       // The short list overflowed (more than MFX_MAXC slot bests within rounding distance of the optimum: massive
