@@ -74,6 +74,16 @@ struct ProjC {   // filter constants of one (atom, extra tuple): see the top of 
   float pn, qn;  // (P + D) |d'|, (1 - D) Q |d'|
 };
 #define MFX_XD 2e-6f   // margin folded into the filter constants: covers the FP32 evaluation of the test
+typedef unsigned int mfx_u32x4 __attribute__((ext_vector_type(4)));
+// one 16-byte LDS read per (atom, tuple) record (the records sit at 16-byte aligned LDS addresses: see the carve-up)
+__device__ __forceinline__ ProjC mfx_ldc(const ProjC* p) {
+  const mfx_u32x4 r = *(const mfx_u32x4*)__builtin_assume_aligned(p, 16);
+  ProjC c;
+  c.u = __longlong_as_double((long long)(((unsigned long long)r[1] << 32) | r[0]));
+  c.pn = __uint_as_float(r[2]);
+  c.qn = __uint_as_float(r[3]);
+  return c;
+}
 struct ProjB {   // threshold-independent part of the filter constants of one (atom, extra tuple), computed once per voxel
   double u;      // as ProjC::u (entry ntup of an atom: its d . f / |f|)
   float np, zp;  // |d'| (0: d' vanishes, the atom passes with every partner) and d'.y' / |d'|
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
           const double a22 = s_A22[j], y2 = s_Y2[j];
           const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
           // ---- filter: which tuples of the lane's four pairs can reach the threshold at all (see the top of the file)
-          float bmax[4] = {-1.0f, -1.0f, -1.0f, -1.0f};   // >= 0: some tuple of the pair passes
+          unsigned sgn[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};   // sign bit cleared: some tuple of the pair passes
           double accf[4];
           const ProjC* cc = s_colc + (buf * 16 + lc) * ntup;
           const ProjC* rc = s_rowc + (wave * 16 + lg) * ntup;
@@ -484,18 +494,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
 #pragma unroll
             for (int r = 0; r < 4; ++r) accf[r] = HASF ? fma(-s_rowf[wave * 16 + lg + 4 * r], uf2, acc[r]) : acc[r];
             const ProjC* r0p = rc, *r1p = rc + 4 * ntup, *r2p = rc + 8 * ntup, *r3p = rc + 12 * ntup;
+#pragma unroll 2
             for (int t = 0; t < ntup; ++t) {
-              const ProjC c2 = cc[t];
-              const ProjC c10 = r0p[t], c11 = r1p[t], c12 = r2p[t], c13 = r3p[t];
-              bmax[0] = fmaxf(bmax[0], fmaf(-c10.qn, c2.qn, fmaf(c10.pn, c2.pn, -(float)fma(-c10.u, c2.u, accf[0]))));
-              bmax[1] = fmaxf(bmax[1], fmaf(-c11.qn, c2.qn, fmaf(c11.pn, c2.pn, -(float)fma(-c11.u, c2.u, accf[1]))));
-              bmax[2] = fmaxf(bmax[2], fmaf(-c12.qn, c2.qn, fmaf(c12.pn, c2.pn, -(float)fma(-c12.u, c2.u, accf[2]))));
-              bmax[3] = fmaxf(bmax[3], fmaf(-c13.qn, c2.qn, fmaf(c13.pn, c2.pn, -(float)fma(-c13.u, c2.u, accf[3]))));
+              const ProjC c2 = mfx_ldc(cc + t);
+              const ProjC c10 = mfx_ldc(r0p + t), c11 = mfx_ldc(r1p + t), c12 = mfx_ldc(r2p + t), c13 = mfx_ldc(r3p + t);
+              const float b0 = fmaf(-c10.qn, c2.qn, fmaf(c10.pn, c2.pn, -(float)fma(-c10.u, c2.u, accf[0])));
+              const float b1 = fmaf(-c11.qn, c2.qn, fmaf(c11.pn, c2.pn, -(float)fma(-c11.u, c2.u, accf[1])));
+              const float b2 = fmaf(-c12.qn, c2.qn, fmaf(c12.pn, c2.pn, -(float)fma(-c12.u, c2.u, accf[2])));
+              const float b3 = fmaf(-c13.qn, c2.qn, fmaf(c13.pn, c2.pn, -(float)fma(-c13.u, c2.u, accf[3])));
+              // "some tuple passes" = some b has its sign bit clear: AND of the bit patterns, one instruction per test
+              sgn[0] &= __float_as_uint(b0); sgn[1] &= __float_as_uint(b1);
+              sgn[2] &= __float_as_uint(b2); sgn[3] &= __float_as_uint(b3);
             }
           }
           unsigned pass[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pass[r] = bmax[r] >= 0.0f ? 1u : 0u;
+          for (int r = 0; r < 4; ++r) pass[r] = (sgn[r] >> 31) ^ 1u;
 #ifdef MFX_STAMPS
           if (a.stamps) {   // diagnostics: tuples that pass the filter / (wave, row group) scoring passes executed
             const int np_ = (int)(pass[0] + pass[1] + pass[2] + pass[3]);   // pairs with a passing tuple
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
               }
               for (int t = 0; t < ntup; ++t) {
                 {   // the filter again, for this tuple alone (the pass above only kept "some tuple passes")
-                  const ProjC c2 = cc[t], c1 = rc[4 * r * ntup + t];
+                  const ProjC c2 = mfx_ldc(cc + t), c1 = mfx_ldc(rc + 4 * r * ntup + t);
                   if (!(fmaf(-c1.qn, c2.qn, fmaf(c1.pn, c2.pn, -(float)fma(-c1.u, c2.u, accf[r]))) >= 0.0f)) continue;
                 }
                 const int cx = x0 + t;
