@@ -17,6 +17,7 @@
 #include "extras.hip"
 #include "rotate.hip"
 #include "solve_generic.hip"
+#include "solve_k3.hip"
 #include "mc_average.hip"
 #include "mfx_device.h"
 
@@ -552,6 +553,39 @@ static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_p
   return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented", K, has_csf, has_ear);
 }
 
+// Launch sequence of the explicit-dictionary solver on device buffers.  Three sub-dictionaries with many triples go
+// through solve_k3.hip (Gram on FP64 MFMA, relaxed-bound screen, candidate list); k3 = its extra buffers (thr, ncand,
+// nblocks_dev), or null for the plain one-thread-per-tuple scan.
+struct K3Bufs { unsigned long long* thr; int* ncand; int* nblocks_dev; double2* st3; };
+static size_t k3_buf_bytes(long N3) { return 64 + sizeof(double2) * (size_t)N3; }
+static K3Bufs k3_bufs(char* p) { return K3Bufs{(unsigned long long*)p, (int*)(p + 16), (int*)(p + 32), (double2*)(p + 64)}; }
+static bool k3_applies(const SolveArgs& a) { return a.Kp == 3 && a.ntuples >= (1L << 18) && a.sizes[0] >= 16 && a.sizes[1] >= 16 && a.sizes[2] >= 16; }
+static int launch_solver(SolveArgs a, const K3Bufs* k3, hipStream_t st) {
+  if (k3) {
+    K3Args k{};
+    a.nblocks_dev = k3->nblocks_dev; a.scan_enable = k3->ncand + 1; a.gram_ranking_only = 1;
+    k.s = a; k.thr = k3->thr; k.ncand = k3->ncand; k.st3 = k3->st3; k.cand_score = a.blk_score; k.cand_tuple = a.blk_tuple;
+    HIPCHK(hipMemsetAsync(k3->thr, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(k3->ncand, 0, 2 * sizeof(int), st));
+    const int nt = (a.Ntot + 63) / 64;
+    hipLaunchKernelGGL(mfx_k3_gram_kernel, dim3(nt, nt), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_k3_aty_kernel, dim3((a.Ntot + 2 + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_k3_st3_kernel, dim3((unsigned)((a.sizes[2] + 255) / 256)), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3_pairs_kernel, dim3(2048), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3_screen_kernel, dim3((unsigned)((a.sizes[1] + 31) / 32), (unsigned)((a.sizes[0] + 31) / 32)), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3_publish_kernel, dim3(1), dim3(64), 0, st, k, k3->nblocks_dev);
+    hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, st, a);   // exits at once unless the list overflowed
+    hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, st, a);
+  } else {
+    const long work = (long)a.Ntot * a.Ntot + a.Ntot + 2;
+    hipLaunchKernelGGL(mfx_gram_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, st, a);
+  }
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
 // Three fascicles (BASELINE config 5; opt-in, MFModel.fit itself stops at two): no fused kernel yet - voxel after voxel
 // the rotated dictionaries are materialised into one row-major [M x (K N + extras)] matrix on the device and go through
 // the explicit-dictionary solver (solve_generic.hip: Gram, one thread per index tuple, exact finalize in the
@@ -573,13 +607,17 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   }
   a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
   a.nblocks = (int)std::min<long>(16384, (ntup + 255) / 256);
-  StreamMem dA(st), dG(st), dAty(st), dysq(st), dbs(st), dbt(st), dw(st), dsub(st), dobj(st), dyrec(st);
+  const bool k3 = k3_applies(a);
+  const size_t nlist = k3 ? (size_t)MFX_K3_CAP : (size_t)a.nblocks;
+  StreamMem dA(st), dG(st), dAty(st), dysq(st), dbs(st), dbt(st), dw(st), dsub(st), dobj(st), dyrec(st), dk3(st);
+  HIPCHK(dk3.alloc(k3_buf_bytes(N)));
+  K3Bufs kb = k3_bufs(dk3.as<char>());
   HIPCHK(dA.alloc(sizeof(double) * (size_t)M * Ntot));
   HIPCHK(dG.alloc(sizeof(double) * (size_t)Ntot * Ntot));
   HIPCHK(dAty.alloc(sizeof(double) * Ntot));
   HIPCHK(dysq.alloc(sizeof(double) * 2));
-  HIPCHK(dbs.alloc(sizeof(double) * a.nblocks));
-  HIPCHK(dbt.alloc(sizeof(long) * a.nblocks));
+  HIPCHK(dbs.alloc(sizeof(double) * nlist));
+  HIPCHK(dbt.alloc(sizeof(long) * nlist));
   HIPCHK(dw.alloc(sizeof(double) * MFX_GK));
   HIPCHK(dsub.alloc(sizeof(long) * MFX_GK));
   HIPCHK(dobj.alloc(sizeof(double)));
@@ -598,10 +636,7 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
     hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, st, p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
                        dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
     a.y = d_Y + (size_t)v * M;
-    const long work = Ntot * Ntot + Ntot + 2;
-    hipLaunchKernelGGL(mfx_gram_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, st, a);
+    if (int rc = launch_solver(a, k3 ? &kb : nullptr, st)) return rc;
     PackArgs pa{};
     pa.w = a.w; pa.sub = a.sub; pa.minobj = a.minobj; pa.yrec = a.yrec; pa.y = a.y;
     pa.M = M; pa.K = K; pa.has_csf = has_csf; pa.E = E; pa.maxfasc = maxfasc; pa.csf_on = csf_on; pa.ear_on = ear_on;
@@ -863,14 +898,17 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
   if (Ntot > 30000) return fail(MFX_ERR_UNSUPPORTED, "explicit solver supports up to 30000 columns (got %ld)", Ntot);
   a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
   a.nblocks = (int)std::min<long>(8192, (ntup + 255) / 256);
+  const bool k3 = k3_applies(a);
+  const size_t nlist = k3 ? (size_t)MFX_K3_CAP : (size_t)a.nblocks;
   std::vector<double> Ac((size_t)M * Ntot);
   for (int k = 0; k < M; ++k) std::memcpy(&Ac[(size_t)k * Ntot], A + (size_t)k * lda, sizeof(double) * Ntot);
   double *dA = nullptr, *dy = nullptr, *dG = nullptr, *dAty = nullptr, *dysq = nullptr, *dbs = nullptr, *dw = nullptr,
          *dobj = nullptr, *dyrec = nullptr;
   long *dbt = nullptr, *dsub = nullptr;
+  char* dk3 = nullptr;
   auto cleanup = [&]() {
     (void)hipFree(dA); (void)hipFree(dy); (void)hipFree(dG); (void)hipFree(dAty); (void)hipFree(dysq); (void)hipFree(dbs);
-    (void)hipFree(dw); (void)hipFree(dobj); (void)hipFree(dyrec); (void)hipFree(dbt); (void)hipFree(dsub);
+    (void)hipFree(dw); (void)hipFree(dobj); (void)hipFree(dyrec); (void)hipFree(dbt); (void)hipFree(dsub); (void)hipFree(dk3);
   };
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(MFX_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } } while (0)
   SCHK(hipMalloc(&dA, sizeof(double) * Ac.size()));
@@ -878,20 +916,21 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
   SCHK(hipMalloc(&dG, sizeof(double) * (size_t)Ntot * Ntot));
   SCHK(hipMalloc(&dAty, sizeof(double) * Ntot));
   SCHK(hipMalloc(&dysq, sizeof(double) * 2));
-  SCHK(hipMalloc(&dbs, sizeof(double) * a.nblocks));
-  SCHK(hipMalloc(&dbt, sizeof(long) * a.nblocks));
+  SCHK(hipMalloc(&dbs, sizeof(double) * nlist));
+  SCHK(hipMalloc(&dbt, sizeof(long) * nlist));
   SCHK(hipMalloc(&dw, sizeof(double) * MFX_GK));
   SCHK(hipMalloc(&dsub, sizeof(long) * MFX_GK));
   SCHK(hipMalloc(&dobj, sizeof(double)));
   SCHK(hipMalloc(&dyrec, sizeof(double) * M));
+  SCHK(hipMalloc(&dk3, k3_buf_bytes(dicsizes[Kp - 1])));
   SCHK(hipMemcpy(dA, Ac.data(), sizeof(double) * Ac.size(), hipMemcpyHostToDevice));
   SCHK(hipMemcpy(dy, y, sizeof(double) * M, hipMemcpyHostToDevice));
   a.A = dA; a.y = dy; a.G = dG; a.Aty = dAty; a.ysq = dysq; a.blk_score = dbs; a.blk_tuple = dbt;
   a.w = dw; a.sub = dsub; a.minobj = dobj; a.yrec = dyrec;
-  const long work = Ntot * Ntot + Ntot + 2;
-  hipLaunchKernelGGL(mfx_gram_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, nullptr, a);
-  hipLaunchKernelGGL(mfx_tuple_scan, dim3(a.nblocks), dim3(256), 0, nullptr, a);
-  hipLaunchKernelGGL(mfx_tuple_finalize, dim3(1), dim3(256), 0, nullptr, a);
+  {
+    K3Bufs kb = k3_bufs(dk3);
+    if (int rc = launch_solver(a, k3 ? &kb : nullptr, nullptr)) { cleanup(); return rc; }
+  }
   SCHK(hipGetLastError());
   SCHK(hipDeviceSynchronize());
   std::vector<long> hsub(MFX_GK);

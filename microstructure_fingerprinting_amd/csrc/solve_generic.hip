@@ -31,6 +31,10 @@ struct SolveArgs {
   double* blk_score;  // [nblocks]
   long* blk_tuple;    // [nblocks]
   int nblocks;
+  // three-dictionary fast path (solve_k3.hip); all null / 0 otherwise
+  const int* nblocks_dev;   // device-side number of entries in blk_score / blk_tuple (< 0: use nblocks)
+  const int* scan_enable;   // the full scan below runs only when this device flag is set
+  int gram_ranking_only;    // G was summed on the matrix pipe: the finalize stage re-sums what it needs sequentially
   // outputs
   double* w;       // [Kp]
   long* sub;       // [Kp]
@@ -134,6 +138,7 @@ __device__ inline double mfx_tuple_score(const SolveArgs& a, const int col[MFX_G
 __global__ __launch_bounds__(256) void mfx_tuple_scan(SolveArgs a) {
   __shared__ double s_sc[256];
   __shared__ long s_t[256];
+  if (a.scan_enable && !*a.scan_enable) return;   // (three-dictionary fast path: only after a candidate-list overflow)
   double best = 0.0;
   long bt = -1;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < a.ntuples; t += (long)gridDim.x * 256) {
@@ -171,17 +176,23 @@ __global__ __launch_bounds__(256) void mfx_tuple_finalize(SolveArgs a) {
   const int tid = threadIdx.x;
   const int n = a.Kp, N = a.Ntot, M = a.M;
   const double y_sq = (n == 1 || n >= 4) ? a.ysq[1] : a.ysq[0];  // np.sum(y**2) in _1/_4up, sequential in _2/_3
-  if (tid == 0) {
+  const int nb = (a.nblocks_dev && *a.nblocks_dev >= 0) ? *a.nblocks_dev : a.nblocks;
+  {
     double mx = 0.0;
-    for (int b = 0; b < a.nblocks; ++b) mx = fmax(mx, a.blk_score[b]);
-    s_max = mx;
+    for (int b = tid; b < nb; b += 256) mx = fmax(mx, a.blk_score[b]);
+    s_res[tid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 256; ++i) mx = fmax(mx, s_res[i]);
+      s_max = mx;
+    }
   }
   __syncthreads();
   const double thr = s_max - 1e-9 * y_sq;
   double bres = INFINITY, bw[MFX_GK];
   long bkey = -1, btt = -1;
   for (int k = 0; k < MFX_GK; ++k) bw[k] = 0.0;
-  for (int b = tid; b < a.nblocks; b += 256) {
+  for (int b = tid; b < nb; b += 256) {
     const long t = a.blk_tuple[b];
     if (t < 0 || a.blk_score[b] < thr) continue;
     int col[MFX_GK];
@@ -203,6 +214,16 @@ __global__ __launch_bounds__(256) void mfx_tuple_finalize(SolveArgs a) {
         }
         return rr;
       };
+      if (a.gram_ranking_only) {
+        // the Gram came from the matrix pipe: the reference's sequential sums (mf_utils.py:503-535) for this triple
+        double g11 = 0, g12 = 0, g13 = 0, g22 = 0, g23 = 0, g33 = 0, y1 = 0, y2 = 0, y3 = 0;
+        for (int k = 0; k < M; ++k) {
+          const double d1 = a.A[k * a.lda + col[0]], d2 = a.A[k * a.lda + col[1]], d3 = a.A[k * a.lda + col[2]], yk = a.y[k];
+          g11 += d1 * d1; g22 += d2 * d2; g33 += d3 * d3; g12 += d1 * d2; g13 += d1 * d3; g23 += d2 * d3;
+          y1 += yk * d1; y2 += yk * d2; y3 += yk * d3;
+        }
+        nnls3_cramer(y_sq, g11, g12, g13, g22, g23, g33, y1, y2, y3, explicit_res, w, res);
+      } else
       nnls3_cramer(y_sq, G[(long)col[0] * N + col[0]], G[(long)col[0] * N + col[1]], G[(long)col[0] * N + col[2]],
                    G[(long)col[1] * N + col[1]], G[(long)col[1] * N + col[2]], G[(long)col[2] * N + col[2]], a.Aty[col[0]],
                    a.Aty[col[1]], a.Aty[col[2]], explicit_res, w, res);

@@ -547,3 +547,34 @@ def test_fit_over_rotate_atom_plan_vs_oracle():
         w, sub, tot, mo, yrec = orc.solve_exhaustive_posweights(np.ascontiguousarray(A), Y3[v], np.array([sel.size] * 3))
         assert np.array_equal(g3[v, 4:7], sub.astype(float)), (v, g3[v], sub)
         assert np.allclose(g3[v, 1:4], w / w.sum(), rtol=1e-6, atol=1e-9)
+
+
+def test_three_dictionaries_fast_path_vs_oracle():
+    """solve_exhaustive_posweights(A, y, [N, N, N]) on the fast three-dictionary path (solve_k3.hip: Gram on FP64 MFMA,
+    relaxed-bound screen of all N^3 triples, candidate list, exact finalize) against the oracle's
+    solve_exhaustive_posweights_3: N = 128 (2.1e6 triples) incl. a signal made of two atoms only and of one atom only (every
+    triple sharing the active atoms ties: the first hit in the reference's i3 -> i1 -> i2 order must win), noise-free data."""
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from microstructure_fingerprinting_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(33)
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000], [30, 30, 30])
+    N, M = 128, sch.shape[0]
+    dic = synth.make_dictionary(rng, sch, N)
+    T = orc.init_tables(dic, sch, Z)
+    for case in range(6):
+        dirs = synth.unit_vectors(rng, 3)
+        A = np.ascontiguousarray(np.concatenate([orc.interp(sch, d, T) for d in dirs], axis=1))
+        at = rng.integers(0, N, 3)
+        nu = rng.dirichlet(np.ones(3))
+        if case == 1: nu = np.array([0.6, 0.4, 0.0])
+        if case == 2: nu = np.array([0.0, 1.0, 0.0])
+        y = 500.0 * sum(nu[k] * A[:, k * N + at[k]] for k in range(3))
+        if case != 3:
+            y = y + rng.normal(0, 500.0 / 30.0, M)
+        sizes = np.array([N, N, N])
+        w, sub, tot, mo, yrec = mfu.solve_exhaustive_posweights(A, y, sizes)
+        wr, subr, totr, mor, yrecr = orc.solve_exhaustive_posweights(A, y, sizes)
+        assert np.array_equal(sub, subr), (case, sub, subr, w, wr)
+        assert np.allclose(w, wr, rtol=1e-9, atol=1e-9) and np.isclose(mo, mor, rtol=1e-9, atol=1e-9 * float(y @ y))
+        assert np.allclose(yrec, yrecr, rtol=1e-9, atol=1e-9)
