@@ -5,9 +5,11 @@
 #include "mfx_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -668,11 +670,16 @@ extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const dou
 // ---- host-buffer voxel loop: pinned staging + chunked H2D on a copy stream overlapped with the kernels on a compute
 // stream (reference loop: mf.py:976-1032).  `rows` (optional) fuses the reference's mask gather `data[mask > 0]`
 // (mf.py:644, 1020-1022) into the staging copy: voxel v's signal is the M doubles at Y + rows[v] * M.
+static void pipe_release(MfxThread& T) {
+  for (int q = 0; q < 2; ++q) { if (T.stage[q]) (void)hipHostFree(T.stage[q]); T.stage[q] = nullptr; }
+  T.stage_bytes = 0;
+  for (int q = 0; q < 4; ++q) { if (T.pool[q]) (void)hipFree(T.pool[q]); T.pool[q] = nullptr; T.pool_bytes[q] = 0; }
+}
+
 static int pipe_setup(int device, size_t want_bytes) {
   MfxThread& T = mfx_thread();
   if (T.pipe_device != device) {
-    for (int q = 0; q < 2; ++q) { if (T.stage[q]) (void)hipHostFree(T.stage[q]); T.stage[q] = nullptr; }
-    T.stage_bytes = 0;
+    pipe_release(T);
     if (T.s_copy) (void)hipStreamDestroy(T.s_copy);
     if (T.s_comp) (void)hipStreamDestroy(T.s_comp);
     T.s_copy = T.s_comp = nullptr;
@@ -691,6 +698,49 @@ static int pipe_setup(int device, size_t want_bytes) {
   return MFX_OK;
 }
 
+// grow-only device buffer `slot` of the calling thread's pipeline (valid after pipe_setup on the same device)
+static int pool_get(int slot, size_t bytes, void** out) {
+  MfxThread& T = mfx_thread();
+  if (T.pool_bytes[slot] < bytes) {
+    if (T.pool[slot]) HIPCHK(hipFree(T.pool[slot]));
+    T.pool[slot] = nullptr;
+    T.pool_bytes[slot] = 0;
+    const size_t want = bytes + bytes / 8;   // head room: slabs of a volume differ a little in size
+    HIPCHK(hipMalloc(&T.pool[slot], want));
+    T.pool_bytes[slot] = want;
+  }
+  *out = T.pool[slot];
+  return MFX_OK;
+}
+
+extern "C" int mfx_thread_release(void) {
+  MfxThread& T = mfx_thread();
+  if (T.pipe_device < 0) return MFX_OK;
+  int cur = 0;
+  HIPCHK(hipGetDevice(&cur));
+  HIPCHK(hipSetDevice(T.pipe_device));
+  if (T.s_copy) (void)hipStreamSynchronize(T.s_copy);
+  if (T.s_comp) (void)hipStreamSynchronize(T.s_comp);
+  pipe_release(T);
+  HIPCHK(hipSetDevice(cur));
+  return MFX_OK;
+}
+
+namespace {
+struct PoolPtr {     // borrowed pointer into the thread's buffer pool
+  void* p = nullptr;
+  template <class U> U* as() const { return (U*)p; }
+};
+struct HostTrace {   // MFX_HOST_TRACE=1: stage times of mfx_fit_batch on stderr (developer diagnostics)
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  HostTrace() : on(std::getenv("MFX_HOST_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) const {
+    if (on) std::fprintf(stderr, "[mfx_fit_batch] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+  }
+};
+}  // namespace
+
 extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K,
                                   const uint8_t* csf, const uint8_t* ear, const double* peaks, int maxfasc, int csf_on,
                                   int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
@@ -705,41 +755,54 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   const int M = p->d.M;
   const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   if (V == 0) return MFX_OK;
-  // chunks of ~32 MB of signal; per chunk the voxels are binned by class (K, csf, ear); the direction check runs once
-  // per batch on the host (the reference checks per voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
+  // chunks of up to ~32 MB of signal, the first ones smaller (1/8, 1/4, 1/2 of that) so that the first kernel starts
+  // after a short staging copy; per chunk the voxels are binned by class (K, csf, ear); the direction check runs
+  // once per batch on the host (the reference checks per voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
+  HostTrace tr;
   const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, ((int64_t)32 << 20) / ((int64_t)M * 8)));
-  const int64_t nch = (V + CH - 1) / CH;
+  std::vector<int64_t> cstart;                   // first voxel of every chunk, then V
+  for (int64_t v0 = 0, n = std::max<int64_t>(1024, CH / 8); v0 < V; n = std::min<int64_t>(CH, 2 * n)) {
+    cstart.push_back(v0);
+    v0 += std::min<int64_t>(n, V - v0);
+  }
+  cstart.push_back(V);
+  const int64_t nch = (int64_t)cstart.size() - 1;
   std::vector<int> list((size_t)V);              // voxel lists, chunk-major then class-major
   std::vector<int> cnt((size_t)nch * 16, 0);
   {
     std::vector<uint8_t> cls((size_t)V);
-    for (int64_t v = 0; v < V; ++v) {
-      const int k = K[v];
-      if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
-      const int c = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
-      if ((c && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
-      for (int f = 0; f < k && !p->d.normalise; ++f) {   // (explicit rotate_atom plans normalise the direction themselves)
-        const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
-        const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        if (!(std::fabs(1 - nrm) <= 1e-3))
-          return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
+    for (int64_t c = 0; c < nch; ++c)
+      for (int64_t v = cstart[c]; v < cstart[c + 1]; ++v) {
+        const int k = K[v];
+        if (k < 0 || k > maxfasc) return fail(MFX_ERR_ARG, "voxel %lld: numfasc %d outside 0..%d", (long long)v, k, maxfasc);
+        const int cf = (csf && csf[v]) ? 1 : 0, e = (ear && ear[v]) ? 1 : 0;
+        if ((cf && !csf_on) || (e && !ear_on)) return fail(MFX_ERR_ARG, "voxel %lld has a CSF/EAR flag but csf_on/ear_on is 0", (long long)v);
+        for (int f = 0; f < k && !p->d.normalise; ++f) {   // (explicit rotate_atom plans normalise the direction themselves)
+          const double* d = peaks + (size_t)v * 3 * maxfasc + 3 * f;
+          const double nrm = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+          if (!(std::fabs(1 - nrm) <= 1e-3))
+            return fail(MFX_ERR_DIR_NORM, "Orientation vector of the new signal must have unit norm. Detected %g.", nrm);
+        }
+        cls[(size_t)v] = (uint8_t)(k * 4 + cf * 2 + e);
+        ++cnt[(size_t)c * 16 + cls[(size_t)v]];
       }
-      cls[(size_t)v] = (uint8_t)(k * 4 + c * 2 + e);
-      ++cnt[(size_t)(v / CH) * 16 + cls[(size_t)v]];
-    }
     std::vector<size_t> pos((size_t)nch * 16);
     size_t acc = 0;
     for (size_t q = 0; q < pos.size(); ++q) { pos[q] = acc; acc += (size_t)cnt[q]; }
-    for (int64_t v = 0; v < V; ++v) list[pos[(size_t)(v / CH) * 16 + cls[(size_t)v]]++] = (int)v;
+    for (int64_t c = 0; c < nch; ++c)
+      for (int64_t v = cstart[c]; v < cstart[c + 1]; ++v) list[pos[(size_t)c * 16 + cls[(size_t)v]]++] = (int)v;
   }
+  tr.mark("voxels binned");
   if (int rc = pipe_setup(p->t->device, (size_t)CH * M * sizeof(double))) return rc;
   MfxThread& T = mfx_thread();
-  DevMem dY, dpk, dpar, dlist, dsc, dse;
-  HIPCHK(dY.alloc(sizeof(double) * (size_t)V * M));
-  HIPCHK(dpk.alloc(sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1)));
-  HIPCHK(dpar.alloc(sizeof(double) * (size_t)V * num_params));
-  HIPCHK(dlist.alloc(sizeof(int) * (size_t)V));
-  // everything below is stream-ordered; any failure drains both streams before the buffers above are released
+  PoolPtr dY, dpk, dpar, dlist;
+  DevMem dsc, dse;
+  if (int rc = pool_get(0, sizeof(double) * (size_t)V * M, &dY.p)) return rc;
+  if (int rc = pool_get(1, sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1), &dpk.p)) return rc;
+  if (int rc = pool_get(2, sizeof(double) * (size_t)V * num_params, &dpar.p)) return rc;
+  if (int rc = pool_get(3, sizeof(int) * (size_t)V, &dlist.p)) return rc;
+  tr.mark("buffers ready");
+  // everything below is stream-ordered; any failure drains both streams before returning
   auto run = [&]() -> int {
     if (maxfasc > 0) HIPCHK(hipMemcpyAsync(dpk.p, peaks, sizeof(double) * (size_t)V * 3 * maxfasc, hipMemcpyHostToDevice, T.s_comp));
     HIPCHK(hipMemcpyAsync(dlist.p, list.data(), sizeof(int) * (size_t)V, hipMemcpyHostToDevice, T.s_comp));
@@ -762,17 +825,20 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
     }
     size_t off = 0;
     for (int64_t c = 0; c < nch; ++c) {
-      const int64_t v0 = c * CH, nv = std::min<int64_t>(CH, V - v0);
+      const int64_t v0 = cstart[c], nv = cstart[c + 1] - v0;
       double* stg = (double*)T.stage[c & 1];
       if (c >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[c & 1]));   // the copy that last used this staging buffer is done
+      tr.mark("  staging buffer free");
       if (rows) {
         for (int64_t v = 0; v < nv; ++v) std::memcpy(stg + (size_t)v * M, Y + (size_t)rows[v0 + v] * M, sizeof(double) * M);
       } else {
         std::memcpy(stg, Y + (size_t)v0 * M, sizeof(double) * (size_t)nv * M);
       }
+      tr.mark("  chunk gathered");
       HIPCHK(hipMemcpyAsync(dY.as<double>() + (size_t)v0 * M, stg, sizeof(double) * (size_t)nv * M, hipMemcpyHostToDevice, T.s_copy));
       HIPCHK(hipEventRecord(T.ev_h2d[c & 1], T.s_copy));
       HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[c & 1], 0));
+      tr.mark("  copy queued");
       for (int q = 0; q < 16; ++q) {
         const int n = cnt[(size_t)c * 16 + q];
         if (!n) continue;
@@ -780,13 +846,16 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
                                    (q >> 1) & 1, q & 1, xs[q & 3], maxfasc, csf_on, ear_on, dpar.as<double>(), T.s_comp)) return rc;
         off += (size_t)n;
       }
+      tr.mark("  kernels queued");
     }
     if (int rc = mfx_fb_end(T.s_comp)) return rc;
+    tr.mark("all chunks queued");
     HIPCHK(hipMemcpyAsync(params_out, dpar.p, sizeof(double) * (size_t)V * num_params, hipMemcpyDeviceToHost, T.s_comp));
     return MFX_OK;
   };
   int rc = run();
   const hipError_t e1 = hipStreamSynchronize(T.s_copy), e2 = hipStreamSynchronize(T.s_comp);
+  tr.mark("done");
   if (rc == MFX_OK && (e1 != hipSuccess || e2 != hipSuccess))
     rc = fail(MFX_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return rc;

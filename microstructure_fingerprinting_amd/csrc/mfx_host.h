@@ -44,6 +44,11 @@ struct MfxThread {
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev_h2d[2] = {nullptr, nullptr};
   int pipe_device = -1;
+  // device buffers of mfx_fit_batch (signals, directions, parameters, voxel lists): kept between calls and only ever
+  // grown, so that a volume fitted slab by slab does not pay an allocation and a (synchronising) release per call;
+  // mfx_thread_release() returns them
+  void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pool_bytes[4] = {0, 0, 0, 0};
 };
 
 MfxThread& mfx_thread();

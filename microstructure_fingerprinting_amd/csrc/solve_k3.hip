@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
   const SolveArgs& a = k.s;
   __shared__ K3C s_c[2][32][MFX_K3_KB];   // [side][atom][i3 in block]  (64 KB)
   __shared__ double s_aa[2][32], s_ay[2][32];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int N = a.Ntot;
   const int N1 = (int)a.sizes[0], N2 = (int)a.sizes[1], N3 = (int)a.sizes[2];
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;

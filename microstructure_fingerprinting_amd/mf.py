@@ -178,7 +178,8 @@ class MFModel():
             nii_affine = aff
         img_shape = mask_arr.shape
         roi = mask_arr > 0
-        ROI_size = int(np.sum(roi))
+        roi_index = np.flatnonzero(roi.reshape(-1))     # ROI order == np.where(mask > 0) (C order)
+        ROI_size = int(roi_index.shape[0])
         if ROI_size == 0:
             raise ValueError("No voxel detected in mask. Please provide a non-empty mask.")
         if data_arr.shape[:-1] != img_shape:
@@ -214,7 +215,8 @@ class MFModel():
             if pk.shape[-1] > maxfasc * 3 and VRB >= 1:
                 print("Ignoring last %d value(s) along last dimension of peaks, as max number of axon populations "
                       "in mask is %d." % (pk.shape[-1] - maxfasc * 3, maxfasc))
-            peaks_roi = np.ascontiguousarray(pk[roi, :3 * maxfasc], dtype=np.float64)
+            peaks_roi = np.ascontiguousarray(np.asarray(pk).reshape(-1, pk.shape[-1])[roi_index, :3 * maxfasc],
+                                             dtype=np.float64)
         elif colat_longit is not None or tensors is not None:
             arg = colat_longit if colat_longit is not None else tensors
             dims = ((2,),) if colat_longit is not None else ((6,), (1, 6))
@@ -248,8 +250,8 @@ class MFModel():
         else:
             raise RuntimeError("At least one of peaks, colat_longit and tensors must be specified.")
         for k in range(maxfasc):   # missing peak where numfasc demands one (ref:803-815)
-            l1 = np.sum(np.abs(peaks_roi[numfasc_roi >= k + 1, 3 * k:3 * k + 3]), axis=1)
-            n0 = int(np.sum(l1 == 0))
+            zero_k = ~np.any(peaks_roi[:, 3 * k:3 * k + 3], axis=1)
+            n0 = int(np.count_nonzero(zero_k & (numfasc_roi >= k + 1))) if zero_k.any() else 0
             if n0 > 0:
                 raise ValueError("Detected %d voxel(s) in which the main orientation of axon population %d/%d was a "
                                  "zero vector, although numfasc specifies the presence of that population."
@@ -308,7 +310,7 @@ class MFModel():
         # numbers: the library gathers the rows while it stages the upload (the reference's data[mask > 0], ref:644)
         if isinstance(data_arr, np.ndarray) and data_arr.dtype == np.float64 and data_arr.flags.c_contiguous:
             Y = data_arr.reshape(-1, num_seq)
-            rows = np.flatnonzero(roi.reshape(-1)).astype(np.int64)
+            rows = roi_index.astype(np.int64, copy=False)
         else:
             Y = np.ascontiguousarray(data_arr[roi], dtype=np.float64)
             rows = None
@@ -325,7 +327,8 @@ class MFModel():
         if VRB >= 2:
             print("Estimation performed in %g second(s)." % (time.time() - st))
         fitinfo = {'maxfasc': maxfasc, 'csf_on': csf_on, 'ear_on': ear_on, 'affine': nii_affine, 'mask': mask_arr,
-                   'fasc_propnames': [x.strip() for x in self.dic['fasc_propnames']], 'peaks_roi': peaks_roi}
+                   'fasc_propnames': [x.strip() for x in self.dic['fasc_propnames']], 'peaks_roi': peaks_roi,
+                   'roi_index': roi_index}
         for n in fitinfo['fasc_propnames']:
             fitinfo['_dict_' + n] = self.dic[n]
         if ear_on:
@@ -384,14 +387,19 @@ class MFModelFit():
     def __init__(self, fitinfo, model_params, verbose=0):
         self.affine = fitinfo['affine']
         nf, csf_on, ear_on, mask = fitinfo['maxfasc'], fitinfo['csf_on'], fitinfo['ear_on'], fitinfo['mask']
-        roi = mask > 0
         ROI_size = model_params.shape[0]
-        assert ROI_size == np.sum(roi), 'Inconsistent mask and model parameter array'
+        flat = fitinfo.get('roi_index')            # flat indices of the ROI voxels (== np.where(mask > 0) order)
+        if flat is None:
+            flat = np.flatnonzero(np.asarray(mask) > 0)
+        assert ROI_size == flat.shape[0], 'Inconsistent mask and model parameter array'
         self.params_in_mask = model_params
+        whole = ROI_size == int(np.prod(mask.shape))
 
         def to_map(vals, extra=()):
+            if whole:     # every voxel is in the ROI: the map is the parameter column itself, reshaped
+                return np.array(vals, dtype=np.float64).reshape(mask.shape + tuple(extra))
             m = np.zeros(mask.shape + tuple(extra))
-            m[roi] = vals
+            m.reshape((-1,) + tuple(extra))[flat] = vals
             return m
         names = ['M0']
         self.M0 = to_map(model_params[:, 0])
@@ -399,12 +407,13 @@ class MFModelFit():
             setattr(self, 'frac_f%d' % k, to_map(model_params[:, k + 1]))
             setattr(self, 'peak_f%d' % k, to_map(fitinfo['peaks_roi'][:, 3 * k:3 * (k + 1)], (3,)))
             names += ['frac_f%d' % k, 'peak_f%d' % k]
+        IDs = [model_params[:, 1 + nf + k].astype(np.intp) for k in range(nf)]
+        active = [model_params[:, k + 1] > 0 for k in range(nf)]
         for prop in fitinfo['fasc_propnames']:     # per-fascicle properties and nu-weighted totals (ref:1106-1129)
             tot = np.zeros(ROI_size)
             for k in range(nf):
                 nu_k = model_params[:, k + 1]
-                ID_k = model_params[:, 1 + nf + k].astype(int)
-                prop_k = fitinfo['_dict_' + prop][ID_k] * (nu_k > 0)
+                prop_k = fitinfo['_dict_' + prop][IDs[k]] * active[k]
                 tot += nu_k * prop_k
                 setattr(self, prop + '_f%d' % k, to_map(prop_k))
                 names.append(prop + '_f%d' % k)

@@ -529,6 +529,34 @@ def test_mixed_classes_reference_golden():
     assert np.all(P[21] == 0)     # K=0, no CSF, no EAR: zeros (mf.py:387-388)
 
 
+def test_host_pipeline_chunks_rows_and_buffer_pool():
+    """mfx_fit_batch_rows on a mixed-class ROI large enough for several chunks (growing chunk sizes), with the ROI
+    gather through `rows`, on re-used and re-grown device buffers, and after mfx_thread_release: every variant returns
+    the rows of the one-call result."""
+    from microstructure_fingerprinting_amd import _lib as L, engine
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    d, sch, sig_csf, sig_ear = _mixed_case()
+    ms = mfu.init_PGSE_multishell_interp(d["dictionary"], d["sch_ms"], Z)
+    plan = ms.plan_for(sch)
+    args = lambda idx: (d["numfasc"][idx], d["csf"][idx], d["ear"][idx], d["peaks"][idx], 2, True, True, sig_csf, sig_ear, int(d["E"]))
+    V0 = d["Y"].shape[0]
+    base = engine.fit_batch(plan, d["Y"], *args(np.arange(V0)))
+    rng = np.random.default_rng(3)
+    for V in (3000, 9000):                    # chunks of 1024, 2048, ... voxels; the second call grows the pool
+        idx = rng.integers(0, V0, V)
+        got = engine.fit_batch(plan, d["Y"][idx], *args(idx))
+        assert np.array_equal(got, base[idx])
+    idx = rng.integers(0, V0, 5000)           # ROI gather: voxel v's signal is row rows[v] of a larger volume
+    vol = np.concatenate([d["Y"], d["Y"][::-1]], axis=0)
+    rows = np.where(rng.random(5000) < 0.5, idx, 2 * V0 - 1 - idx).astype(np.int64)
+    got = engine.fit_batch(plan, vol, *args(idx), rows=rows)
+    assert np.array_equal(got, base[idx])
+    L.check(L.lib().mfx_thread_release())
+    L.check(L.lib().mfx_thread_release())     # idempotent
+    got = engine.fit_batch(plan, d["Y"][idx], *args(idx))
+    assert np.array_equal(got, base[idx])
+
+
 def test_k1_reference_golden_and_oracle():
     from microstructure_fingerprinting_amd import engine
     from microstructure_fingerprinting_amd import mf_utils as mfu

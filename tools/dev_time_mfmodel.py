@@ -32,4 +32,16 @@ for it in range(3):
     fit = model.fit(data, mask, 2, peaks=pk, pgse_scheme=sch, verbose=0)
     t1 = time.time()
     print("MFModel.fit on %d voxels (host arrays in, maps out): %.1f ms -> %.0f voxels/s" % (V, (t1 - t0) * 1e3, V / (t1 - t0)), flush=True)
+if os.environ.get("MFX_DEV_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    fit = model.fit(data, mask, 2, peaks=pk, pgse_scheme=sch, verbose=0)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+Yh = data.reshape(V, -1); Kh = np.full(V, 2, dtype=np.int32)
+for it in range(3):
+    t0 = time.time()
+    engine.fit_batch(plan, Yh, Kh, None, None, peaks, 2, False, False)
+    t1 = time.time()
+    print("engine.fit_batch (mfx_fit_batch_rows) on %d voxels: %.1f ms" % (V, (t1 - t0) * 1e3), flush=True)
 print("mean MSE %.1f (noise variance %.1f)" % (fit.MSE.mean(), (500 / 30) ** 2))
