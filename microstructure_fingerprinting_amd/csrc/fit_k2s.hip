@@ -305,6 +305,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       }
       // single-atom scores are exact: a pair matters only if S(c) >= best1, i.e. S(c~) >= best1 - mrg
       s_thr[0] = mfx_nonneg_bits(best1 - mrg);
+#ifdef MFX_STAMPS_RND   // experiment: a starting threshold handed in by the tool (slot 15), to price the threshold's convergence
+      if (a.stamps) {
+        const double t0 = __longlong_as_double((long long)a.stamps[(size_t)blockIdx.x * 16 + 15]);
+        if (t0 > best1 - mrg) s_thr[0] = mfx_nonneg_bits(t0);
+      }
+#endif
     }
   }
   __syncthreads();
@@ -323,6 +329,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   };
 
   MFX_STAMP(2);
+#ifdef MFX_STAMPS_RND
+  if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+#endif
   double bs1 = 0.0;   // best single atom of D1 among the row tiles this wave has generated
   int bn1 = 0;
   const int nrounds = (ntiles + NW - 1) / NW;
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         s_Zf[n] = act ? (float)z : -1e30f;
         s_cs[n] = (act && a2 > 0.0) ? (float)nrm : 0.0f;
       }
-      // best single atom of D1 so far (first index on ties: rounds and lanes go in increasing n)
+      // best single atom of D1 so far (first index on ties)
       double sb = (act && z > 0.0) ? z * z : 0.0;
       int nb = n;
 #pragma unroll
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       }
       sb = mfx_readlane_f64(sb, 0);
       nb = __builtin_amdgcn_readfirstlane(nb);
-      if (sb > bs1) { bs1 = sb; bn1 = nb; }
+      if (sb > bs1 || (sb == bs1 && sb > 0.0 && nb < bn1)) { bs1 = sb; bn1 = nb; }
       // a pair matters only if it beats every single atom
       if (lane == 0 && sb - mrg > 0.0) atomicMax(&s_thr[0], mfx_nonneg_bits(sb - mrg));
     }
@@ -411,6 +420,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // constants that do not pass (but for the corner cases noted below).  Only a register group with a passing
     // pair runs the FP64 criteria below (one out-of-line copy).
     double thr = 0.0, thr_rows = -1.0;
+#ifdef MFX_STAMPS_RND
+    int dbg_flagged = 0, dbg_groups = 0;   // accumulator tiles / register groups of this wave that reached the FP64 criteria
+#endif
     constexpr float DCF = (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
@@ -463,6 +475,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         mm[q] = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
       }
       if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
+#ifdef MFX_STAMPS_RND
+        ++dbg_flagged;
+#endif
         // ---- exact FP64 pass over the flagged register groups (rare once thr is close to the optimum)
         // the column statistics are ranking-grade anyway (FP32 table): their FP32 copies serve here too
         // (6e-8 relative: ~4e-7 |y|^2 in a score, against the margin of 1e-5 |y|^2)
@@ -470,9 +485,18 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
           if (!__any(mm[q] >= 0.0f)) continue;
+          // the quad's four register groups one by one: the FP32 test again (mm[q] is their maximum), so that only
+          // groups with a passing pair pay the ~40 FP64 instructions below - the seven other waves of the workgroup
+          // wait at the period's barrier for a wave that is in here
+          const f32x4 p1q = *(const f32x4*)(pqw + 8 * q + 4 * lh);
+          const f32x4 q1q = *(const f32x4*)(pqw + 32 + 8 * q + 4 * lh);
 #pragma unroll 1
           for (int gg = 0; gg < 4; ++gg) {
             const int g = 4 * q + gg;
+            if (!__any(fmaf(-q1q[gg], q2, fmaf(p1q[gg], p2, -acc[g])) >= 0.0f)) continue;
+#ifdef MFX_STAMPS_RND
+            ++dbg_groups;
+#endif
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
             const double n12 = (double)s_cs[i] * n2d;
             const double c = n12 > 0.0 ? (double)acc[g] / n12 : 0.0;
@@ -513,6 +537,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     auto scan_tile = [&](const f32x16& acc, int ct) { scan_pre(ct); scan_main(acc, ct); };
 
     if (tail) {
+#ifdef MFX_STAMPS_RND
+      if (a.stamps && tid == 0 && round < 4) a.stamps[(size_t)blockIdx.x * 16 + 2 * round + 1] = __builtin_amdgcn_s_memtime();
+#endif
       thr = __longlong_as_double((long long)s_thr[0]);
       for (int ct = wave; ct < ntiles; ct += NW) {
         const int n = ct * 32 + lr;
@@ -544,6 +571,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         scan_tile(acc, ct);
       }
       __syncthreads();   // all appends of the round are in the ring
+#ifdef MFX_STAMPS_RND
+      if (a.stamps && tid == 0 && round < 4) a.stamps[(size_t)blockIdx.x * 16 + 2 * round + 2] = __builtin_amdgcn_s_memtime();
+#endif
       continue;
     }
 
@@ -619,6 +649,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     };
 
     if (round == 0) MFX_STAMP(3);
+#ifdef MFX_STAMPS_RND   // diagnostic builds: start and end of every round's sweep (tools/dev_stamps_rnd.py)
+    if (a.stamps && tid == 0 && round < 4) a.stamps[(size_t)blockIdx.x * 16 + 2 * round + 1] = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (NB == 3) {
       // ---- one barrier per chunk.  In period c both groups multiply chunk c - group 0 first, group 1 second - and
       // do their VALU work in the other phase: group 0 then screens chunk c and generates its half of chunk c+2,
@@ -694,6 +727,10 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       }
     }
     if (round == 0) MFX_STAMP(5);
+#ifdef MFX_STAMPS_RND
+    if (a.stamps && tid == 0 && round < 4) a.stamps[(size_t)blockIdx.x * 16 + 2 * round + 2] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && lane == 0 && round < 3) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 9 + round], (unsigned long long)dbg_flagged + ((unsigned long long)dbg_groups << 32));
+#endif
   }
   // (the thread index is re-derived here instead of being kept - spilled, 4 KB of scratch per voxel - across the sweep)
   tid = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -840,7 +877,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #ifdef MFX_STAMPS
         if (lane == 0) {
           ++dbg_eval;
-          if (cix >= 1 && cix != s_cnt[3] && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+          if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
         }
 #endif
         __builtin_amdgcn_wave_barrier();
@@ -856,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0 && fabs((y_sq - r) - s_cand[cix].score) > MFX_S_GUARD * mrg) s_cnt[1] = 1;
 #ifdef MFX_STAMPS
         ++dbg_eval;
-        if (cix >= 1 && cix != s_cnt[3] && s_cand[cix].score < 1e299 && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
+        if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
 #endif
       }
     }
