@@ -47,6 +47,33 @@ __device__ __forceinline__ unsigned long long mfx_nonneg_bits(double x) {
   return (unsigned long long)__double_as_longlong(x > 0.0 ? x : 0.0);
 }
 
+// wave-wide maximum of NON-NEGATIVE values, rounded down to FP32, without LDS traffic: four DPP butterfly steps inside
+// the rows of 16 lanes, then the four row values through scalar registers.  (wave_max's __shfl_xor is six dependent
+// ds_bpermute round trips, ~800 of the ~2 600 cycles a register group cost in the FP64 pass while seven waves wait at
+// the period's barrier; the result only feeds the threshold, where 6e-8 relative is 0.6 % of the margin.)
+template <int CTRL>
+__device__ __forceinline__ float mfx_dpp_max_f32(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __int_as_float(o));
+}
+__device__ __forceinline__ double mfx_wave_max_down(double x) {
+  float v = (float)x * (1.0f - 1.2e-7f);   // <= x
+  v = mfx_dpp_max_f32<0xb1>(v);    // quad_perm [1,0,3,2]
+  v = mfx_dpp_max_f32<0x4e>(v);    // quad_perm [2,3,0,1]
+  v = mfx_dpp_max_f32<0x141>(v);   // row_half_mirror
+  v = mfx_dpp_max_f32<0x140>(v);   // row_mirror
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+              r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return (double)fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// 1/x for a positive, normal x to ~1e-14 relative: FP32 reciprocal + one Newton step (an IEEE FP64 division is ~10
+// quarter-rate instructions; the ranking quantities of the FP64 pass carry a margin of 1e-5)
+__device__ __forceinline__ double mfx_rcp_nr(double x) {
+  const double r0 = (double)__builtin_amdgcn_rcpf((float)x);
+  return fma(r0, fma(-x, r0, 1.0), r0);
+}
+
 // value of lane `l` (compile-time constant) in every lane: v_readlane_b32 x 2, no ds_bpermute index arithmetic
 __device__ __forceinline__ double mfx_readlane_f64(double v, int l) {
   const long long b = __double_as_longlong(v);
@@ -438,7 +465,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       sc_z2 = s_Zf[NP + j];
       sc_s = s_cs[NP + j];
     };
+#ifdef MFX_STAMPS_SCAN   // diagnostic builds: wave 0's first pair screen of a voxel in detail (tools/dev_stamps_scan.py)
+    int dbg_calls = 0;
+#define MFX_SCAN_T(k) do { if (a.stamps && round == 0 && dbg_calls == 1 && wave == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFX_SCAN_T(k) do { } while (0)
+#endif
     auto scan_main = [&](const f32x16& acc, int ct) {
+#ifdef MFX_STAMPS_SCAN
+      ++dbg_calls;
+#endif
+      MFX_SCAN_T(0);
       const int j = ct * 32 + lr;
       // row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ct*32 + lr
       thr = fmax(thr, __longlong_as_double((long long)sc_thr));
@@ -474,7 +511,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         for (int u = 0; u < 4; ++u) t[u] = fmaf(-q1q[u], q2, fmaf(p1q[u], p2, -acc[4 * q + u]));
         mm[q] = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
       }
+      MFX_SCAN_T(1);
       if (__any(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])) >= 0.0f)) {
+        MFX_SCAN_T(2);
 #ifdef MFX_STAMPS_RND
         ++dbg_flagged;
 #endif
@@ -499,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #endif
             const int i = rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
             const double n12 = (double)s_cs[i] * n2d;
-            const double c = n12 > 0.0 ? (double)acc[g] / n12 : 0.0;
+            const double c = n12 > 0.0 ? (double)acc[g] * mfx_rcp_nr(n12) : 0.0;
             const double z1 = (double)s_Zf[i];
             const double e1 = fma(-c, z2, z1);
             const double e2 = fma(-c, z1, z2);
@@ -514,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             if (!__any(hit | near)) continue;
             double S = -1.0;
             if (hit) {
-              S = num / den;
+              S = num * mfx_rcp_nr(den);
             } else if (near) {
               // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
               // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
@@ -524,14 +563,22 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             }
             // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
             // a score and never raises it), then append only what still reaches it: no burst of stale entries
-            const double smax = wave_max(hit ? S : 0.0);
+            const double smax = mfx_wave_max_down(hit ? S : 0.0);
             if (smax - 2.0 * mrg > thr) {
               thr = smax - 2.0 * mrg;
               if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
             }
             if ((hit | near) && S >= thr) push(S, i, hit ? j : (j | MFX_S_BOUND));
+#ifdef MFX_STAMPS_SCAN
+            if (a.stamps && round == 0 && dbg_calls == 1 && wave == 0 && lane == 0) {
+              unsigned long long* st = a.stamps + (size_t)blockIdx.x * 16;
+              if (st[15] < 8) st[4 + st[15]] = __builtin_amdgcn_s_memtime();   // end of the first 8 evaluated groups
+              ++st[15];
+            }
+#endif
           }
         }
+        MFX_SCAN_T(3);
       }
     };
     auto scan_tile = [&](const f32x16& acc, int ct) { scan_pre(ct); scan_main(acc, ct); };
@@ -675,8 +722,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       thr = __longlong_as_double((long long)s_thr[0]);
       int b0 = 0;   // buffer of chunk c
       for (int c = 0; c <= ntiles; ++c) {
-#ifdef MFX_STAMPS_HS   // diagnostic builds: start of periods 10..25 of round 1 as seen by wave 0 (tools/dev_stamps_hs.py)
-        if (a.stamps && round == 1 && c >= 10 && c < 26 && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + c - 10] = __builtin_amdgcn_s_memtime();
+#ifdef MFX_STAMPS_HS   // diagnostic builds: start of 16 periods as seen by wave 0 (tools/dev_stamps_hs.py; default: periods 10..25 of round 1)
+#ifndef MFX_HS_ROUND
+#define MFX_HS_ROUND 1
+#define MFX_HS_C0 10
+#endif
+        if (a.stamps && round == MFX_HS_ROUND && c >= MFX_HS_C0 && c < MFX_HS_C0 + 16 && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + c - MFX_HS_C0] = __builtin_amdgcn_s_memtime();
 #endif
         const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;   // buffers of chunks c+1, c+2
         if (grp == 0) {

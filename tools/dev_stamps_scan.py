@@ -1,13 +1,10 @@
-"""Diagnostic: duration of the half-steps of the screening kernel's ping-pong sweep (round 1, half-steps 20..34, wave 0).
-Needs a -DMFX_STAMPS_HS build of the library at microstructure_fingerprinting_amd/libmfx_stamps_hs.so (MFX_STAMPS must
-NOT be defined: the slots overlap)."""
+"""Diagnostic (make stamps_scan -> libmfx_stamps_scan.so): wave 0's first pair screen of every voxel in detail."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from microstructure_fingerprinting_amd import _lib as L
-HS_ROUND, HS_C0 = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 10)   # make stamps_hs HS_ROUND=.. HS_C0=..
-L.LIB_PATH = os.path.join(ROOT, "microstructure_fingerprinting_amd", "libmfx_stamps_hs%d_%d.so" % (HS_ROUND, HS_C0))
+L.LIB_PATH = os.path.join(ROOT, "microstructure_fingerprinting_amd", "libmfx_stamps_scan.so")
 from microstructure_fingerprinting_amd import engine, synth
 import bench
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
@@ -35,9 +32,14 @@ for _ in range(2):
     st.zero_()
     L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y.data_ptr(), d_peaks.data_ptr(), 2, 0, 0, None, None, 0, V, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
-raw = st.cpu().numpy().astype(np.float64)[V // 4: 3 * V // 4]
-x = raw[(raw > 0).all(axis=1)]
-d = np.diff(x, axis=1)
-print("periods of round %d from period %d on (wave 0), cycles" % (HS_ROUND, HS_C0))
-print("  median " + " ".join("%5.0f" % v for v in np.median(d, axis=0)))
-print("  mean   " + " ".join("%5.0f" % v for v in np.mean(d, axis=0)))
+raw = st.cpu().numpy()[V // 4: 3 * V // 4].astype(np.float64)
+ok = (raw[:, 0] > 0) & (raw[:, 1] > 0)
+print("voxels with stamps: %d; first screen flagged in %.1f %%" % (ok.sum(), 100 * np.mean(raw[ok, 2] > 0)))
+f = ok & (raw[:, 2] > 0) & (raw[:, 3] > 0)
+x = raw[f]
+print("fast test (entry -> mm[] known):        median %6.0f cycles" % np.median(x[:, 1] - x[:, 0]))
+print("slow path (flag -> end):                median %6.0f  mean %6.0f cycles, groups evaluated: median %d mean %.1f" % (np.median(x[:, 3] - x[:, 2]), np.mean(x[:, 3] - x[:, 2]), np.median(x[:, 15]), x[:, 15].mean()))
+g = x[x[:, 15] >= 8]
+if len(g):
+    d = np.diff(np.concatenate([g[:, 2:3], g[:, 4:12]], axis=1), axis=1)
+    print("flag -> end of group 1, then group by group (voxels with >= 8 groups): " + " ".join("%5.0f" % v for v in np.median(d, axis=0)))
