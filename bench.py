@@ -13,7 +13,7 @@ builds the dictionary tables and broadcasts them once over RCCL.
         --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
 
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries, measured in the same process over a few
-steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4 and 1 (`c4`, `c1`), the
+steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4, 1 and 5 (`c4`, `c1`, `c5`), the
 PCIe-inclusive rate of the host entry point (`host_api`) and the CPU baseline on all host cores.
 """
 import argparse
@@ -43,6 +43,10 @@ L2_TABLE_BYTES_PER_VOXEL = 6 * 200 * 782 * 8.0 + 8 * 32 * 200 * 8.0
 # config 4, sub-dictionaries [782, 782, 1, E]: the C2 Gram + 782^2 E four-column NNLS of ~150 flops
 C4_E = 10
 FLOP_PER_VOXEL_C4 = 244.6e6 + 782.0 * 782.0 * C4_E * 150.0
+# config 5, sub-dictionaries [1500, 1500, 1500] x 300 measurements: three N x N cross-Grams + N^3 three-column solves of the
+# reference's solve_exhaustive_posweights_3 (Cramer 3x3 + residual from the Gram scalars: ~40 flops each, mf_utils.py:540-600)
+C5_N, C5_V = 1500, 16
+FLOP_PER_VOXEL_C5 = 3 * 2.0 * C5_N * C5_N * 300 + 40.0 * float(C5_N) ** 3
 PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_k2s.json")
 
 
@@ -319,6 +323,26 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
                  "unit": "voxels/s", "kernel": "mfx_fit_small_kernel<false>", "kernel_us": round(kms * 1e3, 1) if kms else None,
                  "bound": "launch latency (one 1000-workgroup launch; HBM roofline for reference)",
                  "achieved_GBps": round(byt / dt / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS, "frac": round(byt / dt / 1e9 / PEAK_HBM_GBPS, 6)}
+    # ---- config 5: three fascicles, 1500 atoms x 300 measurements (3.4e9 triples per voxel), rotated dictionaries materialised
+    # per voxel, explicit-dictionary solver with the relaxed-bound triple screen (solve_k3.hip); opt-in maxfasc = 3
+    rng5 = np.random.default_rng(5)
+    sch5 = synth.make_scheme(rng5, 1, [1000, 2000, 3000, 4000], [75, 75, 75, 74])
+    dic5 = synth.make_dictionary(rng5, sch5, C5_N)
+    ms5 = mfu.init_PGSE_multishell_interp(dic5, sch5, np.array([0.0, 0.0, 1.0]))
+    ms5.device = dev.index or 0
+    plan5 = engine.Plan(ms5.device_tables(), scheme=sch5)
+    _, d_pk5, d_Y5 = synth_voxels(plan5, C5_V, C5_N, sch5.shape[0], dev, 7, K=3)
+    o5 = torch.zeros((C5_V, engine.num_params(3, False, False)), dtype=torch.float64, device=dev)
+    dt, kms = timed(lambda: L.check(lib.mfx_fit_batch_dev(plan5.handle(), d_Y5.data_ptr(), d_pk5.data_ptr(), 3, 0, 0, None, None, 0,
+                                                         C5_V, o5.data_ptr(), st)), 2, 1, dev, lib)
+    ach = FLOP_PER_VOXEL_C5 * C5_V / dt / 1e12
+    out["c5"] = {"workload": "C5: %d voxels, 3 fascicles, sub-dictionaries [%d, %d, %d], %d measurements (%.2e triples per voxel)"
+                             % (C5_V, C5_N, C5_N, C5_N, sch5.shape[0], float(C5_N) ** 3),
+                 "value": round(C5_V / dt, 1), "unit": "voxels/s", "ms_per_voxel": round(dt / C5_V * 1e3, 3),
+                 "kernel": "mfx_k3_screen_kernel (+ mfx_k3_gram_kernel, mfx_tuple_finalize), two voxels in flight", "bound": "valu",
+                 "flop_per_voxel": FLOP_PER_VOXEL_C5, "achieved_TFLOPs_algorithmic": round(ach, 2), "peak_TFLOPs": PEAK_FP64_VALU_TFLOPS,
+                 "frac": round(ach / PEAK_FP64_VALU_TFLOPS, 4)}
+    del plan5, d_Y5, d_pk5, o5
     # ---- PCIe-inclusive: the host entry point (pinned double-buffered upload overlapped with the kernels), NumPy buffers in and out
     Yh, pkh = d_Y.cpu().numpy(), np.ascontiguousarray(peaks_h)
     Kh = np.full(V, 2, dtype=np.int32)

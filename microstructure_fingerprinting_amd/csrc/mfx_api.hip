@@ -611,40 +611,79 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   a.nblocks = (int)std::min<long>(16384, (ntup + 255) / 256);
   const bool k3 = k3_applies(a);
   const size_t nlist = k3 ? (size_t)MFX_K3_CAP : (size_t)a.nblocks;
-  StreamMem dA(st), dG(st), dAty(st), dysq(st), dbs(st), dbt(st), dw(st), dsub(st), dobj(st), dyrec(st), dk3(st);
-  HIPCHK(dk3.alloc(k3_buf_bytes(N)));
-  K3Bufs kb = k3_bufs(dk3.as<char>());
-  HIPCHK(dA.alloc(sizeof(double) * (size_t)M * Ntot));
-  HIPCHK(dG.alloc(sizeof(double) * (size_t)Ntot * Ntot));
-  HIPCHK(dAty.alloc(sizeof(double) * Ntot));
-  HIPCHK(dysq.alloc(sizeof(double) * 2));
-  HIPCHK(dbs.alloc(sizeof(double) * nlist));
-  HIPCHK(dbt.alloc(sizeof(long) * nlist));
-  HIPCHK(dw.alloc(sizeof(double) * MFX_GK));
-  HIPCHK(dsub.alloc(sizeof(long) * MFX_GK));
-  HIPCHK(dobj.alloc(sizeof(double)));
-  HIPCHK(dyrec.alloc(sizeof(double) * M));
-  a.A = dA.as<double>(); a.G = dG.as<double>(); a.Aty = dAty.as<double>(); a.ysq = dysq.as<double>();
-  a.blk_score = dbs.as<double>(); a.blk_tuple = dbt.as<long>(); a.w = dw.as<double>(); a.sub = dsub.as<long>();
-  a.minobj = dobj.as<double>(); a.yrec = dyrec.as<double>();
-  // the voxel-independent extra columns sit behind the fascicle blocks (sub-dictionary order of mf.py:391-408)
-  if (NX > 0)
-    HIPCHK(hipMemcpy2DAsync(dA.as<double>() + (size_t)K * N, sizeof(double) * Ntot, X.d.x, sizeof(double) * NX, sizeof(double) * NX, M,
-                            hipMemcpyDeviceToDevice, st));
+  // two voxels in flight on two internal streams, each with its own set of buffers (at config 5: 162 MB of Gram, 11 MB
+  // of dictionary, 16 MB of candidate list per set)
+  constexpr int LANES = 2;   // (3: no further gain, 4: slower - measured at config 5)
+  MfxThread& T = mfx_thread();
+  if (T.lane_device != p->t->device) {
+    for (int l = 0; l < LANES; ++l) { if (T.s_lane[l]) (void)hipStreamDestroy(T.s_lane[l]); T.s_lane[l] = nullptr; }
+    for (int l = 0; l < 3; ++l) { if (T.ev_lane[l]) (void)hipEventDestroy(T.ev_lane[l]); T.ev_lane[l] = nullptr; }
+    for (int l = 0; l < LANES; ++l) HIPCHK(hipStreamCreateWithFlags(&T.s_lane[l], hipStreamNonBlocking));
+    for (int l = 0; l < 3; ++l) HIPCHK(hipEventCreateWithFlags(&T.ev_lane[l], hipEventDisableTiming));
+    T.lane_device = p->t->device;
+  }
+  const int nl = std::min(nvox, LANES);
+  struct Set {
+    StreamMem dA, dG, dAty, dysq, dbs, dbt, dw, dsub, dobj, dyrec, dk3;
+    explicit Set(hipStream_t s) : dA(s), dG(s), dAty(s), dysq(s), dbs(s), dbt(s), dw(s), dsub(s), dobj(s), dyrec(s), dk3(s) {}
+  };
+  Set set0(st), set1(st);   // allocated and released in the order of the caller's stream: before the fork, after the join
+  Set* sets[LANES] = {&set0, &set1};
+  SolveArgs av[LANES];
+  K3Bufs kbv[LANES];
+  for (int l = 0; l < nl; ++l) {
+    Set& S = *sets[l];
+    HIPCHK(S.dk3.alloc(k3_buf_bytes(N)));
+    kbv[l] = k3_bufs(S.dk3.as<char>());
+    HIPCHK(S.dA.alloc(sizeof(double) * (size_t)M * Ntot));
+    HIPCHK(S.dG.alloc(sizeof(double) * (size_t)Ntot * Ntot));
+    HIPCHK(S.dAty.alloc(sizeof(double) * Ntot));
+    HIPCHK(S.dysq.alloc(sizeof(double) * 2));
+    HIPCHK(S.dbs.alloc(sizeof(double) * nlist));
+    HIPCHK(S.dbt.alloc(sizeof(long) * nlist));
+    HIPCHK(S.dw.alloc(sizeof(double) * MFX_GK));
+    HIPCHK(S.dsub.alloc(sizeof(long) * MFX_GK));
+    HIPCHK(S.dobj.alloc(sizeof(double)));
+    HIPCHK(S.dyrec.alloc(sizeof(double) * M));
+    av[l] = a;
+    av[l].A = S.dA.as<double>(); av[l].G = S.dG.as<double>(); av[l].Aty = S.dAty.as<double>(); av[l].ysq = S.dysq.as<double>();
+    av[l].blk_score = S.dbs.as<double>(); av[l].blk_tuple = S.dbt.as<long>(); av[l].w = S.dw.as<double>(); av[l].sub = S.dsub.as<long>();
+    av[l].minobj = S.dobj.as<double>(); av[l].yrec = S.dyrec.as<double>();
+    // the voxel-independent extra columns sit behind the fascicle blocks (sub-dictionary order of mf.py:391-408)
+    if (NX > 0)
+      HIPCHK(hipMemcpy2DAsync(S.dA.as<double>() + (size_t)K * N, sizeof(double) * Ntot, X.d.x, sizeof(double) * NX, sizeof(double) * NX, M,
+                              hipMemcpyDeviceToDevice, st));
+  }
   if (int rc = mfx_prof_begin(st)) return rc;
-  for (int q = 0; q < nvox; ++q) {
+  hipStream_t ls[LANES] = {st, st};
+  if (nl > 1) {   // fork
+    HIPCHK(hipEventRecord(T.ev_lane[2], st));
+    for (int l = 0; l < nl; ++l) { ls[l] = T.s_lane[l]; HIPCHK(hipStreamWaitEvent(ls[l], T.ev_lane[2], 0)); }
+  }
+  int rc_loop = MFX_OK;
+  for (int q = 0; q < nvox && rc_loop == MFX_OK; ++q) {
+    const int l = q % nl;
     const long v = h_list ? h_list[q] : q;
     dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, K);
-    hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, st, p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
-                       dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
-    a.y = d_Y + (size_t)v * M;
-    if (int rc = launch_solver(a, k3 ? &kb : nullptr, st)) return rc;
+    hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, ls[l], p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
+                       sets[l]->dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
+    av[l].y = d_Y + (size_t)v * M;
+    rc_loop = launch_solver(av[l], k3 ? &kbv[l] : nullptr, ls[l]);
+    if (rc_loop != MFX_OK) break;
     PackArgs pa{};
-    pa.w = a.w; pa.sub = a.sub; pa.minobj = a.minobj; pa.yrec = a.yrec; pa.y = a.y;
+    pa.w = av[l].w; pa.sub = av[l].sub; pa.minobj = av[l].minobj; pa.yrec = av[l].yrec; pa.y = av[l].y;
     pa.M = M; pa.K = K; pa.has_csf = has_csf; pa.E = E; pa.maxfasc = maxfasc; pa.csf_on = csf_on; pa.ear_on = ear_on;
     pa.num_params = num_params; pa.out = d_params + (size_t)v * num_params;
-    hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, st, pa);
+    hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, ls[l], pa);
   }
+  if (nl > 1) {   // join (also on the error path: the buffers are released in the order of `st`)
+    for (int l = 0; l < nl; ++l) {
+      const hipError_t e1 = hipEventRecord(T.ev_lane[l], ls[l]);
+      const hipError_t e2 = hipStreamWaitEvent(st, T.ev_lane[l], 0);
+      if ((e1 != hipSuccess || e2 != hipSuccess) && rc_loop == MFX_OK) rc_loop = fail(MFX_ERR_HIP, "stream join failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+  }
+  if (rc_loop != MFX_OK) return rc_loop;
   HIPCHK(hipGetLastError());
   return mfx_prof_end(st);
 }

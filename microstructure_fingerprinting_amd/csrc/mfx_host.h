@@ -49,6 +49,11 @@ struct MfxThread {
   // mfx_thread_release() returns them
   void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pool_bytes[4] = {0, 0, 0, 0};
+  // two internal streams of the voxel-by-voxel three-fascicle path (two voxels in flight: the launch gaps and the
+  // tail of one voxel's kernels are covered by the other's), forked from and joined to the caller's stream by events
+  hipStream_t s_lane[2] = {nullptr, nullptr};
+  hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};   // [lane] join, [2] fork
+  int lane_device = -1;
 };
 
 MfxThread& mfx_thread();

@@ -28,8 +28,10 @@
 typedef double k3_d4 __attribute__((ext_vector_type(4)));
 
 #define MFX_K3_CAP (1 << 20)   // candidate list entries
-#define MFX_K3_KB 64           // i3 values per LDS block
-#define MFX_K3_D 2e-6f         // margin folded into the test constants (FP32 evaluation of the test)
+#define MFX_K3_KBL 4
+#define MFX_K3_KB (1 << MFX_K3_KBL)   // i3 values per LDS block (33 KB of constants: three workgroups per CU)
+#define MFX_K3_QCAP 2048       // queue of passing triples per block (of 32 768)
+#define MFX_K3_D 4e-6f         // margin folded into the test constants (FP32 evaluation of the test and of its constants)
 
 struct K3Args {
   SolveArgs s;                 // the generic solver's view of the problem (A, y, sizes, G, Aty, ysq, outputs)
@@ -138,8 +140,12 @@ __device__ __forceinline__ K3C k3_ldc(const K3C* p) {
 
 __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
   const SolveArgs& a = k.s;
-  __shared__ K3C s_c[2][32][MFX_K3_KB];   // [side][atom][i3 in block]  (64 KB)
+  // [side][atom][i3 in block], 65 KB; the atom stride is padded by one entry: a thread's column constants sit 1 040 bytes
+  // apart (without it: 1 024 bytes, a 32-way bank conflict on every read - the screen was bound by the LDS, 2.8 of 4.3 ms)
+  __shared__ K3C s_c[2][32][MFX_K3_KB + 1];
   __shared__ double s_aa[2][32], s_ay[2][32];
+  __shared__ unsigned short s_q[MFX_K3_QCAP];   // passing triples of the current i3 block: (row << 11) | (column << 6) | i3
+  __shared__ int s_qn;
   const int tid = threadIdx.x;
   const int N = a.Ntot;
   const int N1 = (int)a.sizes[0], N2 = (int)a.sizes[1], N3 = (int)a.sizes[2];
@@ -163,13 +169,14 @@ __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
     s_aa[side][al] = ok ? G[(size_t)col * N + col] : 0.0;
     s_ay[side][al] = ok ? a.Aty[col] : 0.0;
   }
+  if (tid == 0) s_qn = 0;
   __syncthreads();
   double best = 0.0;
   for (int k0 = 0; k0 < N3; k0 += MFX_K3_KB) {
     // ---- constants of the block: 2 x 32 atoms x 64 i3 values, 16 items per thread (coalesced over i3)
     const double T = __longlong_as_double((long long)*(volatile unsigned long long*)k.thr) - eps_abs;
     for (int q = tid; q < 2 * 32 * MFX_K3_KB; q += 256) {
-      const int kk = q & (MFX_K3_KB - 1), al = (q >> 6) & 31, side = q >> 11;
+      const int kk = q & (MFX_K3_KB - 1), al = (q >> MFX_K3_KBL) & 31, side = q >> (MFX_K3_KBL + 5);
       const int k3 = k0 + kk;
       K3C c;
       c.u = 0.0; c.pn = 1e18f; c.qn = 0.0f;                     // beyond the dictionary: passes (and is skipped below)
@@ -185,21 +192,43 @@ __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
         const float Tp = (float)(T - z3 * z3) * (1.0f - 2e-7f);   // what the two projected atoms must reach
         c.u = u;
         if (n2 > 1e-10 * s_aa[side][al]) {
-          const double np = sqrt(n2);
-          const float npf = (float)np, z = (float)(zn / np);
-          const bool always = !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 1e-6f));
-          const float rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 4e-7f);
+          // |d'| and z = d'.y'/|d'| in FP32 from one reciprocal square root (1 ulp): relative errors <= 3e-7, inside
+          // the margin D and the factors below (an FP64 sqrt and division here cost as much as the 64 tests they serve)
+          const float n2f = (float)n2, rs = __builtin_amdgcn_rsqf(n2f);
+          const float npf = n2f * rs, z = (float)zn * rs;
+          const bool always = !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 3e-6f));
+          const float rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 1e-6f);
           const float P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
           const float Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
-          c.pn = always ? 1e18f : (P + MFX_K3_D) * npf * (1.0f + 2e-7f);
-          c.qn = always ? 0.0f : Q * ((1.0f - MFX_K3_D) * npf) * (1.0f - 2e-7f);
+          c.pn = always ? 1e18f : (P + MFX_K3_D) * npf * (1.0f + 6e-7f);
+          c.qn = always ? 0.0f : Q * ((1.0f - MFX_K3_D) * npf) * (1.0f - 6e-7f);
         }
       }
       s_c[side][al][kk] = c;
     }
     __syncthreads();
-    // ---- the tests: 4 pairs per thread x 64 i3
+    // ---- the tests: 4 pairs per thread x 64 i3.  What passes goes to a queue in LDS and is scored afterwards by
+    // all threads side by side: scored on the spot, one or two lanes of a wave walk through score3 (~150 FP64
+    // instructions, three dependent reads of G) while the other 62 idle, in most of the 64 iterations.
     const int nk = min(MFX_K3_KB, N3 - k0);
+    auto score_triple = [&](int il, int jq, int kk) {
+      const int i = i0 + il, jj = j0 + jq;
+      if (i >= N1 || jj >= N2) return;
+      const int c3 = N1 + N2 + k0 + kk;
+      const double s = score3(s_aa[0][il], G[(size_t)i * N + N1 + jj], G[(size_t)i * N + c3], s_aa[1][jq], G[(size_t)(N1 + jj) * N + c3],
+                              G[(size_t)c3 * N + c3], s_ay[0][il], s_ay[1][jq], a.Aty[c3]);
+      const double Tn = __longlong_as_double((long long)*(volatile unsigned long long*)k.thr) - eps_abs;
+      if (s >= Tn && s > 0.0) {
+        const int slot = atomicAdd(&k.ncand[0], 1);
+        if (slot < MFX_K3_CAP) {
+          k.cand_score[slot] = s;
+          k.cand_tuple[slot] = ((long)i * N2 + jj) * N3 + (k0 + kk);   // itertools order: last index fastest (mfx_decode)
+        } else {
+          k.ncand[1] = 1;   // overflow: the full scan takes over
+        }
+        if (s > best) { best = s; k3_raise(k.thr, s); }
+      }
+    };
     for (int kk = 0; kk < nk; ++kk) {
       const K3C c2 = k3_ldc(&s_c[1][jl][kk]);
       unsigned hit = 0u;
@@ -209,31 +238,23 @@ __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
         const float b = fmaf(-c1.qn, c2.qn, fmaf(c1.pn, c2.pn, -(float)fma(-c1.u, c2.u, a12[r])));
         hit |= (b >= 0.0f) ? (1u << r) : 0u;
       }
-      if (hit) {   // (rare once T is close to the optimum) score the passing triples from the Gram
-        const int c3 = N1 + N2 + k0 + kk;
-        const double a33 = G[(size_t)c3 * N + c3], y3 = a.Aty[c3];
-        const double a23 = (j < N2) ? G[(size_t)(N1 + j) * N + c3] : 0.0;
-        const double a22 = s_aa[1][jl], y2 = s_ay[1][jl];
+      if (hit) {
         for (int r = 0; r < 4; ++r) {
-          const int i = i0 + il0 + 8 * r;
-          if (!((hit >> r) & 1u) || i >= N1 || j >= N2) continue;
-          const double a13 = G[(size_t)i * N + c3];
-          const double s = score3(s_aa[0][il0 + 8 * r], a12[r], a13, a22, a23, a33, s_ay[0][il0 + 8 * r], y2, y3);
-          const double Tn = __longlong_as_double((long long)*(volatile unsigned long long*)k.thr) - eps_abs;
-          if (s >= Tn && s > 0.0) {
-            const int slot = atomicAdd(&k.ncand[0], 1);
-            if (slot < MFX_K3_CAP) {
-              k.cand_score[slot] = s;
-              k.cand_tuple[slot] = ((long)i * N2 + j) * N3 + (k0 + kk);   // itertools order: last index fastest (mfx_decode)
-            } else {
-              k.ncand[1] = 1;   // overflow: the full scan takes over
-            }
-            if (s > best) { best = s; k3_raise(k.thr, s); }
-          }
+          if (!((hit >> r) & 1u)) continue;
+          const int slot = atomicAdd(&s_qn, 1);
+          if (slot < MFX_K3_QCAP) s_q[slot] = (unsigned short)(((il0 + 8 * r) << 11) | (jl << 6) | kk);
+          else score_triple(il0 + 8 * r, jl, kk);   // queue full (threshold still far from the optimum): on the spot
         }
       }
     }
     __syncthreads();
+    const int nq = min(s_qn, MFX_K3_QCAP);
+    for (int q = tid; q < nq; q += 256) {
+      const unsigned e = s_q[q];
+      score_triple((int)(e >> 11), (int)((e >> 6) & 31u), (int)(e & 63u));
+    }
+    __syncthreads();
+    if (tid == 0) s_qn = 0;
   }
 }
 

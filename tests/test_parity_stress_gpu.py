@@ -578,3 +578,56 @@ def test_three_dictionaries_fast_path_vs_oracle():
         assert np.array_equal(sub, subr), (case, sub, subr, w, wr)
         assert np.allclose(w, wr, rtol=1e-9, atol=1e-9) and np.isclose(mo, mor, rtol=1e-9, atol=1e-9 * float(y @ y))
         assert np.allclose(yrec, yrecr, rtol=1e-9, atol=1e-9)
+
+
+def test_c5_full_size_properties():
+    """BASELINE config 5 at its full size - three fascicles, 1500 atoms x 300 measurements, 3.4e9 triples per voxel -
+    through mfx_fit_batch_dev (two voxels in flight).  The oracle would need hours per voxel here, so the checks are
+    size-independent properties: (i) a noise-free voxel made of three atoms returns exactly those atoms, its weights and a
+    zero residual; (ii) for noisy voxels the returned triple's objective, recomputed on the host from the oracle's
+    rotation and a three-column NNLS, equals the reported MSE, and no triple obtained by exchanging one atom of the
+    planted or of the returned solution for a neighbour does better (local optimality of an exhaustive search)."""
+    import torch
+    from microstructure_fingerprinting_amd import engine
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from microstructure_fingerprinting_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(55)
+    sch = synth.make_scheme(rng, 1, [1000, 2000, 3000, 4000], [75, 75, 75, 74])
+    N, M = 1500, sch.shape[0]
+    assert M == 300
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    T = orc.init_tables(dic, sch, Z)
+    V = 6
+    peaks = np.concatenate([synth.unit_vectors(rng, V) for _ in range(3)], axis=1)
+    atoms = rng.integers(0, N, (V, 3))
+    nu = rng.dirichlet(np.ones(3) * 3, V)
+    D = [[orc.interp(sch, peaks[v, 3 * k:3 * k + 3], T) for k in range(3)] for v in range(V)]     # [V][3] of [M, N]
+    Y = np.stack([500.0 * sum(nu[v, k] * D[v][k][:, atoms[v, k]] for k in range(3)) for v in range(V)])
+    Y[2:] += rng.normal(0, 500.0 / 30.0, (V - 2, M))
+    dev = torch.device("cuda", 0)
+    out = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 3).cpu().numpy()
+
+    def objective(v, ids):
+        A = np.stack([D[v][k][:, ids[k]] for k in range(3)], axis=1)
+        w, _ = orc.nnls(A, Y[v])
+        r = Y[v] - A @ w
+        return float(r @ r), w
+    for v in range(V):
+        M0, fr, ids, mse = out[v, 0], out[v, 1:4], out[v, 4:7].astype(int), out[v, 7]
+        res, w = objective(v, ids)
+        assert np.isclose(mse * M, res, rtol=1e-7, atol=1e-9 * float(Y[v] @ Y[v])), (v, mse * M, res)
+        assert np.allclose(M0 * fr, w, rtol=1e-6, atol=1e-7 * M0)
+        if v < 2:     # noise-free: the planted triple, exactly
+            assert np.array_equal(ids, atoms[v]), (v, ids, atoms[v])
+            assert np.allclose(M0 * fr, 500.0 * nu[v], rtol=1e-8) and res <= 1e-12 * float(Y[v] @ Y[v])
+        else:         # nobody in the neighbourhood of the planted or the returned triple does better
+            assert res <= objective(v, atoms[v])[0] * (1 + 1e-12)
+            for base in (atoms[v], ids):
+                for k in range(3):
+                    for dlt in (-2, -1, 1, 2):
+                        alt = np.array(base).copy()
+                        alt[k] = (alt[k] + dlt) % N
+                        assert res <= objective(v, alt)[0] * (1 + 1e-12), (v, base, k, dlt)

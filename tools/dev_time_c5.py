@@ -13,7 +13,7 @@ for N in [int(x) for x in (sys.argv[1:] or ["200", "400", "800"])]:
     dic = synth.make_dictionary(rng, sch, N)
     ms = mfu.init_PGSE_multishell_interp(dic, sch, np.array([0, 0, 1.0]))
     plan = ms.plan_for(sch)
-    V = 2
+    V = int(os.environ.get("MFX_DEV_V", "2"))
     _, dpk, dY = bench.synth_voxels(plan, V, N, sch.shape[0], dev, 7, K=3)
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
