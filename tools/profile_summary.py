@@ -34,7 +34,9 @@ out = {"round": rnd,
        "vmem_read_insts_per_voxel": res.get('SQ_INSTS_VMEM_RD', 0) / V, "salu_insts_per_voxel": res.get('SQ_INSTS_SALU', 0) / V,
        "kernel_cycles_per_xcd": cyc_xcd, "cu_cycles_per_voxel": cyc_xcd * 256 / V,
        "mfma_pipe_utilisation": res['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc_xcd,
-       "valu_insts_per_mfma": res['SQ_INSTS_VALU'] / max(res['SQ_INSTS_MFMA'], 1)}
+       "valu_insts_per_mfma": res['SQ_INSTS_VALU'] / max(res['SQ_INSTS_MFMA'], 1),
+       "lds_bank_conflict_cycles_per_voxel": res.get('SQ_LDS_BANK_CONFLICT', 0) / V,
+       "lds_bank_conflict_frac_of_lds_active": res.get('SQ_LDS_BANK_CONFLICT', 0) / max(res.get('SQ_LDS_IDX_ACTIVE', 0), 1)}
 json.dump(out, open(R + '/profiles/r%02d_pmc_traffic_%s.json' % (rnd, tag), 'w'), indent=1)
 ks = sorted(glob.glob(R + '/gpurun_out/prof_stats/runc/*_kernel_stats.csv'), key=os.path.getmtime)
 if ks:
