@@ -132,6 +132,21 @@ int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const double* d_peak
 int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const int64_t* dicsizes, int Kp, const double* y,
                          double* w, int64_t* sub, int64_t* tot, double* min_obj, double* y_rec);
 
+/* ---- "next" row N3: the voxel loop of cleanup_2fascicles(frac1, frac2, peakmode, mu1, mu2, mask) (mf.py:36-335,
+ * loop body mf.py:170-335).  Inputs are the ROI voxels (mask > 0) in np.where order with the orientation descriptors
+ * already turned into direction vectors (the Python wrapper does that as the reference does: colat/longit trigonometry,
+ * DT_vec_to_peaks for tensors): f1, f2 [n] weights, p1, p2 [n x 3] directions.  Per voxel, in the reference's order:
+ * peaks closer than the merge angle (|clip(p1.p2)| > cos_min) are merged into population 0, a population `ratio` times
+ * lighter than the other one and lighter than w_keep is dropped, populations lighter than w_small are dropped, the
+ * survivors are ordered by descending weight.  peaks_out [n x 6], count_out [n] (0, 1 or 2 as doubles, like the
+ * reference's num_fasc_out).  Results equal the reference's bit for bit.                                          */
+int mfx_cleanup_2fascicles(const double* f1, const double* f2, const double* p1, const double* p2, int64_t n,
+                           double cos_min, double ratio, double w_keep, double w_small, double* peaks_out,
+                           double* count_out, int device);
+int mfx_cleanup_2fascicles_dev(const double* d_f1, const double* d_f2, const double* d_p1, const double* d_p2, int64_t n,
+                               double cos_min, double ratio, double w_keep, double w_small, double* d_peaks_out,
+                               double* d_count_out, void* stream);
+
 /* ---- Monte-Carlo signal synthesis (dictionary generation, upstream of fitting): replaces
  * monte_carlo_average(sim_phases, delta_mapping, gscaling, Dscaling, num_spins) (mf_utils.py:2758-2810),
  * the kernel under get_PGSE_from_phases (mf_utils.py:2813-3015).

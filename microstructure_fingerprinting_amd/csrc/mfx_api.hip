@@ -21,6 +21,7 @@
 #include "solve_generic.hip"
 #include "solve_k3.hip"
 #include "mc_average.hip"
+#include "cleanup.hip"
 #include "mfx_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -977,6 +978,44 @@ extern "C" int mfx_rotate_cols(const mfx_plan* p, const double* dirs, const int3
   }
   (void)hipFree(dd); (void)hipFree(dc); (void)hipFree(dout);
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cleanup_2fascicles: the per-voxel selection (ref mf.py:170-335)
+extern "C" int mfx_cleanup_2fascicles_dev(const double* d_f1, const double* d_f2, const double* d_p1, const double* d_p2, int64_t n,
+                                          double cos_min, double ratio, double w_keep, double w_small, double* d_peaks_out,
+                                          double* d_count_out, void* stream) {
+  if (n < 0 || (n > 0 && (!d_f1 || !d_f2 || !d_p1 || !d_p2 || !d_peaks_out || !d_count_out)))
+    return fail(MFX_ERR_ARG, "mfx_cleanup_2fascicles_dev: bad argument");
+  if (n == 0) return MFX_OK;
+  const int64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffff) return fail(MFX_ERR_ARG, "too many voxels for one launch");
+  CleanupArgs a{d_f1, d_f2, d_p1, d_p2, (long)n, cos_min, ratio, w_keep, w_small, d_peaks_out, d_count_out};
+  hipLaunchKernelGGL(mfx_cleanup_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+extern "C" int mfx_cleanup_2fascicles(const double* f1, const double* f2, const double* p1, const double* p2, int64_t n,
+                                      double cos_min, double ratio, double w_keep, double w_small, double* peaks_out,
+                                      double* count_out, int device) {
+  if (n < 0 || (n > 0 && (!f1 || !f2 || !p1 || !p2 || !peaks_out || !count_out)))
+    return fail(MFX_ERR_ARG, "mfx_cleanup_2fascicles: bad argument");
+  if (n == 0) return MFX_OK;
+  if (int rc = require_device(device)) return rc;
+  DevMem din, dout;
+  HIPCHK(din.alloc(sizeof(double) * 8 * (size_t)n));
+  HIPCHK(dout.alloc(sizeof(double) * 7 * (size_t)n));
+  double* b = din.as<double>();
+  HIPCHK(hipMemcpy(b, f1, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b + n, f2, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b + 2 * n, p1, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b + 5 * n, p2, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  if (int rc = mfx_cleanup_2fascicles_dev(b, b + n, b + 2 * n, b + 5 * n, n, cos_min, ratio, w_keep, w_small, dout.as<double>(),
+                                          dout.as<double>() + 6 * n, nullptr)) return rc;
+  HIPCHK(hipMemcpy(peaks_out, dout.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(count_out, dout.as<double>() + 6 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return MFX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

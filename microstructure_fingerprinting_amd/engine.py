@@ -154,3 +154,17 @@ def rotate_columns_dev(plan, d_dirs, d_cols, normalise=False):
     L.check(L.lib().mfx_rotate_cols_dev(plan.handle(), d_dirs.data_ptr(), cols.data_ptr(), B, int(normalise),
                                         out.data_ptr(), st))
     return out
+
+
+def cleanup_select(f1, f2, p1, p2, cos_min, ratio, w_keep, w_small, device=0):
+    """Voxel loop of cleanup_2fascicles (mfx_cleanup_2fascicles; ref mf.py:170-335): weights f1, f2 [n] and directions p1, p2
+    [n x 3] of the ROI voxels -> (peaks [n x 6], count [n])."""
+    f1, f2, p1, p2 = L.f64c(f1), L.f64c(f2), L.f64c(p1), L.f64c(p2)
+    n = f1.shape[0]
+    if f2.shape != (n,) or p1.shape != (n, 3) or p2.shape != (n, 3):
+        raise ValueError("cleanup_select: f1, f2 should have shape (n,), p1, p2 (n, 3)")
+    peaks = np.zeros((n, 6))
+    count = np.zeros(n)
+    L.check(L.lib().mfx_cleanup_2fascicles(L.dptr(f1), L.dptr(f2), L.dptr(p1), L.dptr(p2), n, float(cos_min), float(ratio),
+                                           float(w_keep), float(w_small), L.dptr(peaks), L.dptr(count), int(device)))
+    return peaks, count

@@ -88,48 +88,13 @@ def cleanup_2fascicles(frac1, frac2, peakmode, mu1, mu2, mask, frac12=None):
                          % (peakmode, width, mu1.shape[-1], mu2.shape[-1]))
 
     roi = mask > 0
-    n = int(np.sum(roi))
-    f = np.stack([frac1[roi], frac2[roi]], axis=1).astype(np.float64)      # weights of slots 0 / 1
-    p = [_directions_from(mu1[roi], peakmode), _directions_from(mu2[roi], peakmode)]
-    count = np.full(n, 2.0)
-
-    def drop(slot, where):
-        p[slot][where] = 0.0
-        f[where, slot] = 0.0
-
-    # 1. merge nearly parallel peaks into slot 0
-    dp = np.sum(p[0] * p[1], axis=-1)
-    merge = np.abs(np.clip(dp, -1, 1)) > np.cos(CLEANUP_ANG_MIN * np.pi / 180)
-    if np.any(merge):
-        summed = p[0][merge] + p[1][merge] * np.sign(dp[merge])[:, np.newaxis]
-        p[0][merge] = summed / np.sqrt(np.sum(summed ** 2, axis=1))[:, np.newaxis]
-        f[merge, 0] = frac1[roi][merge] + frac2[roi][merge]
-        drop(1, merge)
-        count[merge] = 1
-    # 2. relatively small population 0: population 1 takes its slot
-    rel0 = (f[:, 1] > CLEANUP_RATIO * f[:, 0]) & (f[:, 0] < CLEANUP_W_KEEP)
-    if np.any(rel0):
-        p[0][rel0] = p[1][rel0]
-        f[rel0, 0] = f[rel0, 1]
-        drop(1, rel0)
-        count[rel0] = (f[rel0, 0] > 0) * 1
-    # 3. relatively small population 1: dropped, weight not transferred
-    rel1 = (f[:, 0] > CLEANUP_RATIO * f[:, 1]) & (f[:, 1] < CLEANUP_W_KEEP)
-    if np.any(rel1):
-        drop(1, rel1)
-        count[rel1] = (f[rel1, 0] > 0) * 1
-    # 4./5. small absolute weights
-    abs0 = f[:, 0] < CLEANUP_W_SMALL
-    if np.any(abs0):
-        drop(0, abs0)
-        count[abs0] = count[abs0] - 1
-    abs1 = f[:, 1] < CLEANUP_W_SMALL
-    if np.any(abs1):
-        drop(1, abs1)
-        count[abs1] = (f[abs1, 0] > 0) * 1
-    # 6. heavier population first; the reference's reversed ascending argsort puts slot 1 first on ties
-    swap = (f[:, 1] >= f[:, 0])[:, np.newaxis]
-    peaks = np.concatenate([np.where(swap, p[1], p[0]), np.where(swap, p[0], p[1])], axis=1)
+    f1 = np.ascontiguousarray(frac1[roi], dtype=np.float64)
+    f2 = np.ascontiguousarray(frac2[roi], dtype=np.float64)
+    p1 = np.ascontiguousarray(_directions_from(mu1[roi], peakmode), dtype=np.float64)
+    p2 = np.ascontiguousarray(_directions_from(mu2[roi], peakmode), dtype=np.float64)
+    # the voxel loop (ref:170-335) runs on the device, one thread per ROI voxel (csrc/cleanup.hip)
+    peaks, count = engine.cleanup_select(f1, f2, p1, p2, np.cos(CLEANUP_ANG_MIN * np.pi / 180), CLEANUP_RATIO,
+                                         CLEANUP_W_KEEP, CLEANUP_W_SMALL)
 
     peaks_out = np.zeros(mask.shape + (6,))
     peaks_out[roi] = peaks

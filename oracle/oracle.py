@@ -300,3 +300,46 @@ def nnls(A, b):
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+def cleanup_select(f1, f2, p1, p2, ang_min_deg=15, ratio=2.5, w_keep=0.20, w_small=0.075):
+    """The voxel loop of cleanup_2fascicles restated with NumPy selects (ref mf.py:170-335): weights f1, f2 [n] and unit
+    directions p1, p2 [n x 3] of the ROI voxels -> (peaks [n x 6], count [n]).  Checked against outputs of the reference
+    (tests/golden/cleanup_cases.npz) in tests/test_cleanup.py; the referee of the device kernel (csrc/cleanup.hip)."""
+    n = f1.shape[0]
+    f = np.stack([f1, f2], axis=1).astype(np.float64)
+    p = [np.array(p1, dtype=np.float64), np.array(p2, dtype=np.float64)]
+    count = np.full(n, 2.0)
+
+    def drop(slot, where):
+        p[slot][where] = 0.0
+        f[where, slot] = 0.0
+    dp = np.sum(p[0] * p[1], axis=-1)
+    merge = np.abs(np.clip(dp, -1, 1)) > np.cos(ang_min_deg * np.pi / 180)
+    if np.any(merge):
+        summed = p[0][merge] + p[1][merge] * np.sign(dp[merge])[:, np.newaxis]
+        p[0][merge] = summed / np.sqrt(np.sum(summed ** 2, axis=1))[:, np.newaxis]
+        f[merge, 0] = f1[merge] + f2[merge]
+        drop(1, merge)
+        count[merge] = 1
+    rel0 = (f[:, 1] > ratio * f[:, 0]) & (f[:, 0] < w_keep)
+    if np.any(rel0):
+        p[0][rel0] = p[1][rel0]
+        f[rel0, 0] = f[rel0, 1]
+        drop(1, rel0)
+        count[rel0] = (f[rel0, 0] > 0) * 1
+    rel1 = (f[:, 0] > ratio * f[:, 1]) & (f[:, 1] < w_keep)
+    if np.any(rel1):
+        drop(1, rel1)
+        count[rel1] = (f[rel1, 0] > 0) * 1
+    abs0 = f[:, 0] < w_small
+    if np.any(abs0):
+        drop(0, abs0)
+        count[abs0] = count[abs0] - 1
+    abs1 = f[:, 1] < w_small
+    if np.any(abs1):
+        drop(1, abs1)
+        count[abs1] = (f[abs1, 0] > 0) * 1
+    swap = (f[:, 1] >= f[:, 0])[:, np.newaxis]     # the reference's reversed ascending argsort puts slot 1 first on ties
+    peaks = np.concatenate([np.where(swap, p[1], p[0]), np.where(swap, p[0], p[1])], axis=1)
+    return peaks, count

@@ -13,6 +13,38 @@ def d():
     return np.load(os.path.join(G, "cleanup_cases.npz"))
 
 
+def test_oracle_cleanup_selection_vs_reference_goldens(d):
+    """The oracle's restatement of the voxel loop (the referee of the device kernel) against the reference's outputs."""
+    from oracle import oracle as orc
+    roi = d["mask"] > 0
+    pk, nf = orc.cleanup_select(d["f1"][roi], d["f2"][roi], d["d1"][roi], d["d2"][roi])
+    assert np.array_equal(nf, d["peaks_nf"][roi]) and np.array_equal(pk, d["peaks_pk"][roi])
+
+
+@pytest.mark.gpu
+def test_cleanup_device_kernel_vs_oracle_large():
+    """2e5 random voxels (all outcomes, exact ties, zero weights, anti-parallel and identical peaks) through the device
+    kernel: bit-identical to the oracle."""
+    from microstructure_fingerprinting_amd import engine, mf as mfm, synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(8)
+    n = 200000
+    p1, p2 = synth.unit_vectors(rng, n), synth.unit_vectors(rng, n)
+    near = rng.random(n) < 0.3                     # crossings around the 15 degree merge angle, both signs
+    ang = np.deg2rad(rng.uniform(0, 30, n))
+    ortho = np.cross(p1, synth.unit_vectors(rng, n)); ortho /= np.linalg.norm(ortho, axis=1)[:, None]
+    p2[near] = (np.cos(ang)[:, None] * p1 + np.sin(ang)[:, None] * ortho)[near] * rng.choice([-1.0, 1.0], n)[near, None]
+    p2[::1000] = p1[::1000]; p2[1::1000] = -p1[1::1000]
+    f1, f2 = rng.uniform(0, 0.6, n), rng.uniform(0, 0.6, n)
+    f2[::7] = f1[::7]; f1[::11] = 0.0; f2[::13] = 0.0; f1[::17] = 0.075; f2[::19] = 0.2
+    got = engine.cleanup_select(f1, f2, p1, p2, np.cos(mfm.CLEANUP_ANG_MIN * np.pi / 180), mfm.CLEANUP_RATIO, mfm.CLEANUP_W_KEEP,
+                                mfm.CLEANUP_W_SMALL)
+    ref = orc.cleanup_select(f1, f2, p1, p2)
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
+    assert set(np.unique(got[1])) == {0.0, 1.0, 2.0}
+
+
+@pytest.mark.gpu
 def test_cleanup_peaks_mode_bit_exact(d):
     import microstructure_fingerprinting_amd as mf
     pk, nf = mf.cleanup_2fascicles(d["f1"], d["f2"], 'peaks', d["d1"].copy(), d["d2"].copy(), d["mask"])
@@ -22,6 +54,7 @@ def test_cleanup_peaks_mode_bit_exact(d):
     assert np.all(pk[d["mask"] == 0] == 0) and np.all(nf[d["mask"] == 0] == 0)
 
 
+@pytest.mark.gpu
 def test_cleanup_colat_and_frac12(d):
     import microstructure_fingerprinting_amd as mf
     f12 = np.stack([d["f1"], d["f2"]], -1)
@@ -31,6 +64,7 @@ def test_cleanup_colat_and_frac12(d):
         assert np.allclose(pk, d["colat_pk"], rtol=0, atol=1e-15)
 
 
+@pytest.mark.gpu
 def test_cleanup_tensor_mode(d):
     import microstructure_fingerprinting_amd as mf
     pk, nf = mf.cleanup_2fascicles(d["f1"], d["f2"], 'tensor', d["T1"][..., None, :], d["T2"], d["mask"])
@@ -53,6 +87,7 @@ def test_cleanup_argument_errors(d):
         mf.cleanup_2fascicles(None, None, 'peaks', d["d1"], d["d2"], d["mask"], frac12=d["f1"][..., None])
 
 
+@pytest.mark.gpu
 def test_cleanup_from_nifti_files(d, tmp_path):
     import microstructure_fingerprinting_amd as mf
     from microstructure_fingerprinting_amd import nifti
