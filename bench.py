@@ -346,12 +346,15 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
     # ---- PCIe-inclusive: the host entry point (pinned double-buffered upload overlapped with the kernels), NumPy buffers in and out
     Yh, pkh = d_Y.cpu().numpy(), np.ascontiguousarray(peaks_h)
     Kh = np.full(V, 2, dtype=np.int32)
-    engine.fit_batch(plan, Yh[:4096], Kh[:4096], None, None, pkh[:4096], 2, False, False)    # staging buffers, streams
+    t0 = time.perf_counter()
+    engine.fit_batch(plan, Yh, Kh, None, None, pkh, 2, False, False)    # first call of the thread: allocates its staging and device buffers
+    dt_first = time.perf_counter() - t0
     t0 = time.perf_counter()
     ph = engine.fit_batch(plan, Yh, Kh, None, None, pkh, 2, False, False)
     dt = time.perf_counter() - t0
-    out["host_api"] = {"value": round(V / dt, 1), "unit": "voxels/s", "what": "mfx_fit_batch_rows on host ndarrays (H2D + kernels + D2H)",
-                       "ms": round(dt * 1e3, 2), "outputs_identical_to_device_path": bool(np.array_equal(ph, d_out.cpu().numpy()))}
+    out["host_api"] = {"value": round(V / dt, 1), "unit": "voxels/s", "what": "mfx_fit_batch_rows on host ndarrays (H2D + kernels + D2H), buffers of the thread in place",
+                       "ms": round(dt * 1e3, 2), "first_call_ms": round(dt_first * 1e3, 2),
+                       "outputs_identical_to_device_path": bool(np.array_equal(ph, d_out.cpu().numpy()))}
     return out
 
 

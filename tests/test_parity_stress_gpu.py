@@ -90,7 +90,7 @@ def test_k2_stress_regimes_vs_oracle_full_size():
     ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
     plan = ms.plan_for(sch)
     N, M = ms.num_subs, sch.shape[0]
-    per = 200
+    per = int(os.environ.get("MFX_STRESS_PER_REGIME", "200"))   # (one-off deep runs: e.g. 2000)
     pk, Ys, names = [], [], []
     for name, snr, deg, nu0 in REGIMES:
         p1 = synth.unit_vectors(rng, per)
