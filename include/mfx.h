@@ -181,7 +181,9 @@ int mfx_debug_last_fallback_count(void);
 int mfx_debug_last_guard_count(void);
 /* Diagnostic: raw counter `which` of the last call: 0 hand-backs / exhaustive passes, 1 guard hand-backs, and for the
  * two-fascicle + CSF/EAR kernel 2 short-listed pairs, 3 family items (one-atom / no-atom supports and ambiguous slots
- * evaluated exactly), summed over the batch. */
+ * evaluated exactly), 4 voxels of the [N, N, 1] screening pipeline handed to the FP64 kernel of the class (ring overflow,
+ * an atom inside the span of the CSF column, list overflow, bound check), 5 of them by the bound check (a listed pair
+ * whose exact score exceeds its screening bound by more than the margin), summed over the batch; which = 0..7. */
 int mfx_debug_last_counter(int which);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
@@ -189,6 +191,9 @@ void mfx_debug_set_k2_screen(int enabled);
  * screening kernel instead of the two-waves-per-SIMD one, 0 never uses the wide kernel (protocols of more than 256
  * measurements then run on the FP64 kernel), any other value: automatic (same as MFX_K2_WIDE in the environment). */
 void mfx_debug_set_k2_wide(int mode);
+/* 0 keeps the two-fascicle + CSF class ([N, N, 1]) on the FP64 kernel instead of the screening pipeline (split-FP16
+ * screening kernel -> short lists -> exact stage); same as MFX_K2X_SCREEN=0 in the environment.  Calling thread only. */
+void mfx_debug_set_k2x_screen(int on);
 /* Diagnostic: short-list size of the FP64 two-fascicle kernel beyond which its exhaustive exact pass runs
  * (default and maximum 256; 0 forces that pass for every voxel -- used by the tests to cover it). */
 void mfx_debug_set_k2_maxc(int maxc);

@@ -60,6 +60,14 @@ struct FitK2Args {
   int* fb_list;         // ... and their voxel indices
   int maxc;             // FP64 kernel: short-list size beyond which the exhaustive exact pass runs (MFX_MAXC; tests lower it)
   int scap;             // screening kernel: ring entries in use (MFX_S_CAP, a power of two; tests lower it to force hand-backs)
+  // screening kernel in its [N, N, 1] form (XC: two fascicles + one fixed extra column, fit_k2s.hip): the column, the
+  // per-voxel short lists it writes for fit_k2x.hip's exact stage, and the first voxel of the launch
+  const double* xc;     // [M] the extra column (CSF signal)
+  struct Cand* xl_cand; // [gridDim.x][xl_cap] short-listed pairs of every voxel of the launch
+  int* xl_cnt;          // [gridDim.x] their number, or -1: voxel handed back
+  double* xl_mrg;       // [gridDim.x] the voxel's screening margin (score units)
+  int xl_cap;
+  int vox_base;         // voxel (or vox_list entry) of block 0
 };
 
 #ifdef MFX_STAMPS

@@ -99,7 +99,17 @@ __device__ __forceinline__ void mfx_split16(float f, _Float16& hi, _Float16& lo)
 
 // BR: the protocol has G-bracketed rows (screening through the plan's virtual shells, exact stage as mfx_eval_br)
 // NB: LDS images of D2 chunks: 3 (one workgroup barrier per chunk) where they fit beside the rest, else 2 (two barriers)
-template <int KS, bool BR = false, int NB = 3>
+// XC: the voxel class has one fixed extra column x besides the two fascicles (sub-dictionaries [N, N, 1]: CSF).  Leaving
+//     x unconstrained turns the problem into a two-atom problem in the orthogonal complement of x: atoms
+//     d' = d - u x^ (u = d.x^, x^ = x/|x|), signal y' = y - (y.x^) x^, and  y.x^^2 + S2(d1', d2'; y')  bounds the score of
+//     every support made of d1, d2 and x from above.  The projected cross product d1'.d2' = d1.d2 - u1 u2 comes out of
+//     the SAME MFMAs: one spare padded measurement row carries -u1 in the A operand and u2 in the B image.  Statistics,
+//     pair screen, FP64 criteria and ring then run unchanged on projected quantities (norms |d'|, z' = d'.y'/|d'|, the
+//     margin DC amplified by max|d|/|d'| of the two dictionaries); the threshold only rises with pairs whose
+//     relaxed solution keeps x's weight non-negative (then it IS a feasible score).  There is no exact stage here: the
+//     ring entries that reach the final threshold go to a per-voxel list for fit_k2x.hip's exact stage (list mode),
+//     which also owns every support with fewer than two fascicle atoms.
+template <int KS, bool BR = false, int NB = 3, bool XC = false>
 __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   constexpr int WG = 512, NW = 8;
   constexpr int MP = KS * 16;  // padded measurement count
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   const int NP = (N + 31) & ~31;  // atoms padded to a multiple of 32
   const int ntiles = NP >> 5;
   const double2* __restrict__ tab = a.T.tab;
-  const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
+  const int vox = a.vox_list ? a.vox_list[a.vox_base + blockIdx.x] : a.vox_base + (int)blockIdx.x;
 
   // ---- LDS carve-up
   _Float16* sBh = (_Float16*)smem;                 // [NB][KS][64][8]  hi halves, fragment order
@@ -135,6 +145,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int* s_r1 = (int*)(s_dG + (BR ? MP : 0));        // [2][MP] upper-shell knot row * ldn, or -1
   int* s_rs = BR ? s_r1 + 2 * MP : s_r0;           // [2][MP] row offsets used by the screening passes
   int* s_evl4 = s_r1 + (BR ? 4 * MP : 0);          // [MFX_S_CAP] exact-stage compaction list, KS < 8 only (else inside the B image)
+  float* s_xf = (float*)(s_evl4 + (KS < 8 ? MFX_S_CAP : 0));   // XC: [MP] x^ (unit extra column, 0 beyond M)
+  float* s_uf = s_xf + (XC ? MP : 0);              // XC: [2][NP] u = d.x^ of the rotated atoms
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -170,6 +182,10 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     }
   }
   if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  if constexpr (XC) {
+    for (int m = tid; m < MP; m += WG) s_xf[m] = (m < M) ? (float)a.xc[m] : 0.0f;
+    if (tid < 2) ((unsigned long long*)s_red)[24 + tid] = 0ull;   // max |d|^2/|d'|^2 of each dictionary (bits of a non-negative double)
+  }
   if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
 
@@ -201,8 +217,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   for (int m = 0; m < M; ++m) y_sq_v += s_y[m] * s_y[m];
   // wave-uniform values that live through the whole kernel go to scalar registers (the vector file is full)
   const double y_sq = mfx_readlane_f64(y_sq_v, 0);
-  const double mrg = mfx_readlane_f64(MFX_S_DC * y_sq, 0);        // |S(c~) - S(c)| <= mrg
-  const double etol = mfx_readlane_f64(MFX_S_DC * sqrt(y_sq), 0); // |e(c~) - e(c)| <= etol
+  // XC: v = the FP32 copy of x; everything is projected on the complement of v: with h = |v|^2, u = d.v / sqrt(h),
+  // yx = y.v / sqrt(h) (y as its FP32 ranking copy, like the statistics)
+  double rsh_v = 1.0, yx_v = 0.0;
+  if constexpr (XC) {
+    double h = 0.0, xy = 0.0;
+    for (int m = 0; m < M; ++m) { const double xv = (double)s_xf[m]; h = fma(xv, xv, h); xy = fma(xv, (double)s_yf[m], xy); }
+    rsh_v = h > 0.0 ? 1.0 / sqrt(h) : 0.0;
+    yx_v = xy * rsh_v;
+  }
+  const double rsh = mfx_readlane_f64(rsh_v, 0), yx = mfx_readlane_f64(yx_v, 0);
+  const double y_sq_p = XC ? fmax(y_sq - yx * yx, 0.0) : y_sq;   // |y'|^2
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
   {
@@ -216,17 +241,24 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     // read once for both purposes: the L2 -> L1 fill rate, ~32 B/clk, is what bounds these passes).
     const int VH = ((N + 1) / 2 + 63) & ~63;
     const int npass = (VH + WG - 1) / WG;
+    // (XC: both dictionaries here - the projected statistics and the amplification of the margin must be known
+    // before the sweep - with u = d.v accumulated beside |d|^2 and d.y)
+#pragma unroll 1
+    for (int kd = XC ? 0 : 1; kd < 2; ++kd) {
+    double ms_cur = 0.0, rm2_cur = 1.0;   // this dictionary's best single score / max |d|^2/|d'|^2 (no runtime-indexed arrays: scratch)
+    int mn_cur = 0;
     for (int p0 = 0; p0 < npass; p0 += 2) {
       int kq[2], nq[2];
       bool wact[2];
-      double a2[2][2], ay[2][2];
+      double a2[2][2], ay[2][2], au[2][2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int v = tid + WG * (p0 + q);
-        kq[q] = 1;
+        kq[q] = kd;
         nq[q] = 2 * v;
         wact[q] = __any((p0 + q < npass) && (nq[q] < N));
         a2[q][0] = a2[q][1] = ay[q][0] = ay[q][1] = 0.0;
+        au[q][0] = au[q][1] = 0.0;
       }
       // software pipeline over groups of four rows: the 8 table loads of the next group are in flight while this
       // group is accumulated (the vector-memory pipe and the FP64 VALU work of this pass each take ~40 k cycles per
@@ -249,6 +281,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       auto accumulate = [&](int m4, auto stc) {
         constexpr int st = decltype(stc)::value;
         const f32x4 yv = *(const f32x4*)(s_yf + m4);
+        f32x4 xv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (XC) xv = *(const f32x4*)(s_xf + m4);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (wact[q]) {
@@ -262,6 +296,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
               ay[q][0] = fma(ye, d0, ay[q][0]);
               a2[q][1] = fma(d1, d1, a2[q][1]);
               ay[q][1] = fma(ye, d1, ay[q][1]);
+              if constexpr (XC) {
+                const double xe = (double)xv[e];
+                au[q][0] = fma(xe, d0, au[q][0]);
+                au[q][1] = fma(xe, d1, au[q][1]);
+              }
             }
           }
         }
@@ -280,15 +319,41 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           const int k = kq[q], n = nq[q] + u;
           if (p0 + q < npass && n < NP) {
             const bool act = n < N;
-            const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
-            const double z = ay[q][u] * inv;
-            s_Zf[k * NP + n] = act ? (float)z : -1e30f;
-            s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
-            const double s = z > 0.0 ? z * z : 0.0;
-            if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
+            if constexpr (!XC) {
+              const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
+              const double z = ay[q][u] * inv;
+              s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+              s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
+              const double s = z > 0.0 ? z * z : 0.0;
+              if (act && s > ms_cur) { ms_cur = s; mn_cur = n; }   // increasing n per thread and dictionary
+            } else {
+              // projected statistics: |d'|^2 = |d|^2 - u^2, d'.y' = d.y - u yx.  An atom (nearly) inside span(x) -
+              // |d'| < |d|/4 - would amplify the margin beyond use: the voxel goes to the FP64 kernel of the class
+              const double uu = au[q][u] * rsh;
+              const double n2p = a2[q][u] - uu * uu;
+              const bool ok = act && a2[q][u] > 0.0;
+              if (ok && !(n2p > a2[q][u] * (1.0 / 16.0))) s_cnt[1] = 1;
+              const bool okp = ok && n2p > 0.0;
+              const double np = okp ? sqrt(n2p) : 0.0;
+              const double inv = okp ? 1.0 / np : 0.0;
+              const double z = (ay[q][u] - uu * yx) * inv;
+              s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+              s_cs[k * NP + n] = okp ? (float)np : 0.0f;
+              s_uf[k * NP + n] = okp ? (float)uu : 0.0f;
+              if (okp) rm2_cur = fmax(rm2_cur, a2[q][u] * inv * inv);
+              // {d, x} with both weights non-negative is a feasible support: its score starts the threshold
+              const bool feas = okp && z > 0.0 && (yx - z * inv * uu) >= 0.0;
+              const double s = feas ? z * z : 0.0;
+              if (s > ms_cur) { ms_cur = s; mn_cur = n; }
+            }
           }
         }
       }
+    }
+    if (kd == 0) { my_s[0] = ms_cur; my_n[0] = mn_cur; } else { my_s[1] = ms_cur; my_n[1] = mn_cur; }
+    if constexpr (XC) {
+      if (rm2_cur > 1.0) atomicMax((unsigned long long*)s_red + 24 + kd, mfx_nonneg_bits(rm2_cur));
+    }
     }
   }
   // best single atom of each dictionary (first index on ties): they stand for every pair whose optimum
@@ -298,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     double* s_bs = s_red;            // [2][8]
     int* s_bn = (int*)(s_red + 16);  // [2][8]
 #pragma unroll
-    for (int k = 1; k < 2; ++k) {
+    for (int k = XC ? 0 : 1; k < 2; ++k) {
       double s = my_s[k];
       int n = my_n[k];
 #pragma unroll
@@ -312,9 +377,24 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (lane == 0) { s_bs[k * 8 + wave] = s; s_bn[k * 8 + wave] = n; }
     }
     __syncthreads();
+  }
+  // margins.  XC: the screening error of the cross product is relative to |d1||d2|, the test works in units of
+  // |d1'||d2'|: amplified by max |d|/|d'| of either dictionary (<= 4 each, see the statistics)
+  double ramp_v = 1.0;
+  if constexpr (XC) {
+    const unsigned long long* rw = (const unsigned long long*)s_red + 24;
+    ramp_v = sqrt(fmax(1.0, __longlong_as_double((long long)rw[0]))) * sqrt(fmax(1.0, __longlong_as_double((long long)rw[1])));
+  }
+  const double ramp = mfx_readlane_f64(ramp_v, 0);
+  const double dc_eff = XC ? MFX_S_DC * ramp : MFX_S_DC;                 // bound on |c~ - c| in the units of the test
+  const double mrg = mfx_readlane_f64(dc_eff * y_sq_p, 0);        // |S(c~) - S(c)| <= mrg
+  const double etol = mfx_readlane_f64(dc_eff * sqrt(y_sq_p), 0); // |e(c~) - e(c)| <= etol
+  {
+    double* s_bs = s_red;            // [2][8]
+    int* s_bn = (int*)(s_red + 16);  // [2][8]
     if (tid == 0) {
       double best1 = 0.0;
-      for (int k = 1; k < 2; ++k) {   // D1's best single atom is known after the last round (see there)
+      for (int k = XC ? 0 : 1; k < 2; ++k) {   // (!XC) D1's best single atom is known after the last round (see there)
         double s = s_bs[k * 8];
         int n = s_bn[k * 8];
         for (int w = 1; w < 8; ++w) {
@@ -323,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
           if (s2 > s || (s2 == s && n2 < n)) { s = s2; n = n2; }
         }
         best1 = fmax(best1, s);
-        if (s > 0.0) {
+        if (!XC && s > 0.0) {   // (XC: supports with fewer than two fascicle atoms belong to the exact kernel's families)
           const int slot = s_cnt[0]++;
           s_cand[slot].score = s + mrg;   // exact single-atom score up to the statistics' rounding: evaluated only if it can win
           s_cand[slot].i = k ? 0 : n;
@@ -379,6 +459,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       const int n = rtc * 32 + lr;
       const int nn = min(n, ldn - 1);
       double a2 = 0.0, ay = 0.0;
+      // XC: the LAST padded measurement row (MP - 1 > M - 1: the launcher sees to that; the table's padded rows are
+      // zero) carries -u1 in the A operand and u2 in the B images - a compile-time position: a test against M per element
+      // is loop-invariant, gets hoisted out of the rounds and costs ~100 spilled registers
+      float um1 = 0.0f;
+      if constexpr (XC) um1 = (rt_valid && n < N) ? -s_uf[n] : 0.0f;
       mfx_static_for<0, KS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
         float2 d[8];
@@ -389,9 +474,13 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         for (int j = 0; j < 8; ++j) {
           float fv = fmaf(d[j].y, s_t0f[16 * ks + 8 * lh + j], d[j].x);
           fv = rt_valid ? fv : 0.0f;
-          const double fd = (double)fv;
-          a2 = fma(fd, fd, a2);
-          ay = fma((double)s_yf[16 * ks + 8 * lh + j], fd, ay);
+          if constexpr (XC) {
+            if constexpr (ks == KS - 1) { if (j == 7) fv = lh ? um1 : fv; }
+          } else {
+            const double fd = (double)fv;
+            a2 = fma(fd, fd, a2);
+            ay = fma((double)s_yf[16 * ks + 8 * lh + j], fd, ay);
+          }
           _Float16 x, y;
           mfx_split16(fv, x, y);
           vh[j] = x; vl[j] = y;
@@ -400,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         afh[ks] = vh; afl[ks] = vl;
         __builtin_amdgcn_sched_barrier(0);
       });
+      if constexpr (!XC) {   // (XC: the statistics of both dictionaries come from phase 1, and one-atom supports are not this kernel's)
       a2 += __shfl_xor(a2, 32);
       ay += __shfl_xor(ay, 32);
       const bool act = rt_valid && n < N;
@@ -426,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (sb > bs1 || (sb == bs1 && sb > 0.0 && nb < bn1)) { bs1 = sb; bn1 = nb; }
       // a pair matters only if it beats every single atom
       if (lane == 0 && sb - mrg > 0.0) atomicMax(&s_thr[0], mfx_nonneg_bits(sb - mrg));
+      }
     }
 
     // pair screen of one 32x32 accumulator tile against column tile ct (used by the LDS sweep and by the tail round)
@@ -450,7 +541,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #ifdef MFX_STAMPS_RND
     int dbg_flagged = 0, dbg_groups = 0;   // accumulator tiles / register groups of this wave that reached the FP64 criteria
 #endif
-    constexpr float DCF = (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
+    const float DCF = XC ? (float)(((double)MFX_S_DC + 2e-6) * ramp) * (1.0f + 2e-7f)
+                         : (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
       Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
@@ -557,13 +649,22 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             } else if (near) {
               // ill-conditioned pair: interval upper bound of S over |c - c~| <= DC;
               // S = z2^2 + e1^2/den = z1^2 + e2^2/den for two positive weights
-              const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
+              const double dlo = den - 2.0 * dc_eff - dc_eff * dc_eff;
               const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
               S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
             }
             // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
             // a score and never raises it), then append only what still reaches it: no burst of stale entries
-            const double smax = mfx_wave_max_down(hit ? S : 0.0);
+            bool feas = hit;
+            if constexpr (XC) {
+              // a relaxed score may raise the threshold only if it is the score of a feasible support: x's weight
+              // w_x = yx - w1 u1 - w2 u2, w_i = e_i / (den |d_i'|), clearly non-negative (e carries an error <= etol,
+              // u/|d'| <= 4)
+              const double q1 = (double)s_uf[i] * mfx_rcp_nr(fmax((double)s_cs[i], 1e-300));
+              const double q2 = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
+              feas = hit && (fma(-e2, q2, fma(-e1, q1, yx * den)) >= 8.0 * etol);
+            }
+            const double smax = mfx_wave_max_down(feas ? S : 0.0);
             if (smax - 2.0 * mrg > thr) {
               thr = smax - 2.0 * mrg;
               if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
@@ -591,6 +692,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       for (int ct = wave; ct < ntiles; ct += NW) {
         const int n = ct * 32 + lr;
         const int nn = min(n, ldn - 1);
+        float tail_u2 = 0.0f;
+        if constexpr (XC) tail_u2 = s_uf[NP + n];
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -607,7 +710,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             _Float16 x, y;
-            mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x), x, y);
+            float fv = fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x);
+            if constexpr (XC && ks == KS - 1) { if (j == 7) fv = lh ? tail_u2 : fv; }   // the spare row carries u2
+            mfx_split16(fv, x, y);
             bh[j] = x; bl[j] = y;
           }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ks], bh, acc, 0, 0, 0);
@@ -653,13 +758,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (gact) {
         const int c0 = 2 * (tg & 15);
         h8 hi0, lo0, hi1, lo1;
+        float gu0 = 0.0f, gu1 = 0.0f;   // XC: u2 of the item's two atoms, for the spare row M
+        if constexpr (XC) { gu0 = s_uf[NP + ch * 32 + c0]; gu1 = s_uf[NP + ch * 32 + c0 + 1]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = GT ? g_t[GT ? e : 0] : s_t0f[MP + 8 * gq + e];
           _Float16 x, y;
-          mfx_split16(fmaf(gd[e][1], t, gd[e][0]), x, y);
+          float v0 = fmaf(gd[e][1], t, gd[e][0]), v1 = fmaf(gd[e][3], t, gd[e][2]);
+          if constexpr (XC) { if (e == 7) { const bool spare = (gq == 2 * KS - 1); v0 = spare ? gu0 : v0; v1 = spare ? gu1 : v1; } }
+          mfx_split16(v0, x, y);
           hi0[e] = x; lo0[e] = y;
-          mfx_split16(fmaf(gd[e][3], t, gd[e][2]), x, y);
+          mfx_split16(v1, x, y);
           hi1[e] = x; lo1[e] = y;
         }
         // fragments of atoms c0, c0+1 are adjacent: 32 contiguous bytes per lane, conflict-free
@@ -852,13 +961,41 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   const int ncand = nappend > a.scap ? a.scap : nappend;
   const double thr_fin = __longlong_as_double((long long)s_thr[0]);
   const double lost = __longlong_as_double((long long)s_thr[1]);
+  const int xc_flag = XC ? s_cnt[1] : 0;   // an atom (nearly) inside span(x)
   __syncthreads();   // everyone has read the counters / is done with the B buffers
-  if (nappend > a.scap && lost >= thr_fin) {
+  if ((nappend > a.scap && lost >= thr_fin) || xc_flag) {
     // an entry that could still matter was overwritten: hand the voxel to the FP64 kernel
     if (tid == 0) {
       const int slot = atomicAdd(a.fb_count, 1);
       a.fb_list[slot] = vox;
+      if constexpr (XC) a.xl_cnt[blockIdx.x] = -1;
     }
+    return;
+  }
+  if constexpr (XC) {
+    // the ring entries that reach the final threshold -> this voxel's short list (scores in projected units, + yx^2 in all)
+    int* s_evl = (KS >= 8) ? (int*)((char*)smem + 2048) : s_evl4;
+    if (tid == 0) s_cnt[2] = 0;
+    __syncthreads();
+    for (int cix = tid; cix < ncand; cix += WG)
+      if (s_cand[cix].score >= thr_fin) s_evl[atomicAdd(&s_cnt[2], 1)] = cix;
+    __syncthreads();
+    const int neval = s_cnt[2];
+    if (neval > a.xl_cap) {   // too many near-ties for the list: the FP64 kernel of the class decides
+      if (tid == 0) {
+        const int slot = atomicAdd(a.fb_count, 1);
+        a.fb_list[slot] = vox;
+        a.xl_cnt[blockIdx.x] = -1;
+      }
+      return;
+    }
+    Cand* dst = a.xl_cand + (size_t)blockIdx.x * a.xl_cap;
+    for (int e = tid; e < neval; e += WG) {
+      Cand c = s_cand[s_evl[e]];
+      c.score += yx * yx;
+      dst[e] = c;
+    }
+    if (tid == 0) { a.xl_cnt[blockIdx.x] = neval; a.xl_mrg[blockIdx.x] = mrg; }
     return;
   }
   if (tid == 0) {    // mf_utils.py:327, 382: start from min_obj = y_sq at pair (0,0) with w = 0, strict '<'

@@ -61,6 +61,14 @@ struct FitK2XArgs {
   int xx_in_lds; // the extra columns are staged in LDS (when the 160 KB allow it)
   unsigned long long* stamps;  // diagnostic builds only: [gridDim.x][16] s_memtime stamps (null otherwise)
   int* ovf_count;  // [4] launch counters: [0] voxels that took the exhaustive pass, [2] short-listed pairs, [3] family items
+  // list mode (LIST = true: the pair scan is replaced by the short lists of the screening kernel, fit_k2s.hip XC = true)
+  const Cand* xl_cand;     // [gridDim.x][xl_cap] short-listed pairs; .score bounds the pair's best score from above (up to xl_mrg)
+  const int* xl_cnt;       // [gridDim.x] their number, or -1: the voxel is not this launch's
+  const double* xl_mrg;    // [gridDim.x] the screening margin of the voxel (score units)
+  int xl_cap;
+  int* fb_count;           // hand-back list of the pipeline: a pair that beats its bound sends the voxel to the plain kernel
+  int* fb_list;
+  const int* list_count;   // null, or device word: blocks beyond it exit (plain kernel over a device-side voxel list)
 };
 
 #define MFX_XFAM 64   // family items (see below) per voxel before the exhaustive pass takes over
@@ -96,11 +104,13 @@ struct CandX {
 
 // NW waves per workgroup and NBUF LDS chunk buffers: (8, 2) for M <= 200, (4, 1) for long protocols
 // (one wave per SIMD owns the 512-register file; see fit_k2.hip).
-template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
+template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(FitK2XArgs a) {
   constexpr int MP = KSTEPS * 4;
   constexpr int WG = NW * 64;
   extern __shared__ double smem[];
+  if (a.list_count && a.vox_base + (int)blockIdx.x >= *a.list_count) return;   // workgroup-uniform
+  if constexpr (LIST) { if (a.xl_cnt[blockIdx.x] < 0) return; }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
   const int M = a.P.M, N = a.T.N, ldn = a.T.ldn, NP = ldn, ntiles = NP >> 4;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     const int p = q / MFX_XS, r = q - p * MFX_XS;
     s_Gxx[q] = (p < NX && r < NX) ? a.X.Gxx[p * NX + r] : 0.0;
   }
-  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
   if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
   if (tid < MFX_XS) {
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   if (tid == 0) s_thr[0] = (unsigned long long)__double_as_longlong(gmax_run > 0.0 ? gmax_run : 0.0);
   __syncthreads();   // s_red is reused by the rounds
   // ---- filter constants.  Once per voxel: the threshold-independent part of every (atom, tuple) -> slab wsP
-  for (int q = tid; q < 2 * NP * (ntup + 1); q += WG) {
+  for (int q = tid; q < (LIST ? 0 : 2 * NP * (ntup + 1)); q += WG) {
     const int kn = q / (ntup + 1), t = q - kn * (ntup + 1);
     const int k = kn >= NP, n = kn - k * NP;
     ProjB pb;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   };
   auto gen_chunk = [&](int ch, int buf) { gen_load(ch); gen_store(ch, buf); };
 
-  const int nrounds = (ntiles + NW - 1) / NW;
+  const int nrounds = LIST ? 0 : (ntiles + NW - 1) / NW;
   const double eps_abs = eps_abs_of * y_sq;
   MFX_STAMP(2);
 
@@ -639,6 +649,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
 
   MFX_STAMP(6);
   // ---- one-atom and no-atom supports within rounding distance of the optimum -> family items
+  auto family_detection = [&]() {
   const double thr_final = gmax_run - eps_abs;
   for (int col = tid; col < 2 * NP; col += WG) {
     const int k = col >= NP, n = col - k * NP;
@@ -657,19 +668,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     if (f < MFX_XFAM) { s_fam[f].type = 3; s_fam[f].a = 0; s_fam[f].t = tid; }
   }
   __syncthreads();
+  };
+  if constexpr (!LIST) family_detection();
 
   MFX_STAMP(7);
-  // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
-  const int nappend = s_cnt[0], nfam_app = s_cnt[1];
-  const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
-  // (a voxel in which no support scores above zero keeps the reference's initial state: nothing to evaluate)
-  const bool nothing = !(gmax_run > 0.0);
-  if (tid == 0 && a.ovf_count) {   // diagnostics: short-listed pairs and family items of the launch
-    atomicAdd(a.ovf_count + 2, ncand);
-    atomicAdd(a.ovf_count + 3, nfam_app);
-  }
-  const bool exhaustive = !nothing && (a.maxc == 0 || nappend > a.maxc || nfam_app > MFX_XFAM);   // workgroup-uniform
-  __syncthreads();
   // scratch inside the (now idle) B buffers
   static_assert(NBUF * MP * 16 >= 8 * NW + 16 + MP, "B buffers too small for the exact-stage scratch");
   double* s_rres = (double*)sB;                  // [NW]
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   long key = -1;
   // one tuple (i, j, t) exactly: _3 = Cramer test + explicit residual (mf_utils.py:554-593), _4up = active-set optimum
   // from a sequentially summed Gram + explicit residual (mf_utils.py:640-649); keeps the lexicographic (res, scan key) minimum
-  auto consider = [&](int i, int j, int t) {
+  auto consider = [&](int i, int j, int t) -> double {
     const int c3 = (Kp == 3) ? t : 0, c4 = 1 + t;
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0, a13 = 0.0, a23 = 0.0, a14 = 0.0, a24 = 0.0;
     for (int m = 0; m < M; ++m) {
@@ -717,7 +719,50 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       k = ((long)i * N + j) * E + t;  // itertools.product order, last index fastest
     }
     if (r < res || (r == res && k < key)) { res = r; key = k; w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = u[3]; }
+    return r;
   };
+  if constexpr (LIST) {
+    // ---- list mode: the screening kernel's short list stands for the pair scan.  Every listed pair through the
+    // reference arithmetic at once (the lists are short); the best of their scores joins the one-/no-atom supports
+    // in the running maximum the family rule needs.  A pair that beats the upper bound it was listed with by more than
+    // the screening margin cannot happen if the margin holds: the voxel then goes to the plain kernel (and is counted).
+    const int cnt = a.xl_cnt[blockIdx.x];
+    const Cand* lst = a.xl_cand + (size_t)blockIdx.x * a.xl_cap;
+    const double xmrg = a.xl_mrg[blockIdx.x];
+    bool beaten = false;
+    for (int q = tid; q < cnt * ntup; q += WG) {
+      const int c = q / ntup, t = q - c * ntup;
+      const Cand e = lst[c];
+      const double r = consider(e.i, e.j & 0x3fffffff, t);
+      beaten |= (y_sq - r) > e.score + 1.25 * xmrg;
+    }
+    double lb = (key >= 0) ? y_sq - res : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lb = fmax(lb, __shfl_xor(lb, o));
+    if (lane == 0) s_red[wave] = lb;
+    if (beaten) s_cnt[2] = 1;
+    __syncthreads();
+    for (int c = 0; c < NW; ++c) gmax_run = fmax(gmax_run, s_red[c]);
+    if (s_cnt[2] && tid == 0) {
+      const int slot = atomicAdd(a.fb_count, 1);
+      a.fb_list[slot] = vox;
+      atomicAdd(a.fb_count + 1, 1);
+    }
+    __syncthreads();   // s_red is free again
+    family_detection();
+  }
+  // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
+  const double thr_final = gmax_run - eps_abs;
+  const int nappend = s_cnt[0], nfam_app = s_cnt[1];
+  const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
+  // (a voxel in which no support scores above zero keeps the reference's initial state: nothing to evaluate)
+  const bool nothing = !(gmax_run > 0.0);
+  if (tid == 0 && a.ovf_count) {   // diagnostics: short-listed pairs and family items of the launch
+    atomicAdd(a.ovf_count + 2, LIST ? a.xl_cnt[blockIdx.x] : ncand);
+    atomicAdd(a.ovf_count + 3, nfam_app);
+  }
+  const bool exhaustive = !nothing && (a.maxc == 0 || nappend > a.maxc || nfam_app > MFX_XFAM);   // workgroup-uniform
+  __syncthreads();
   if (exhaustive) {
     // The short list overflowed: nothing above can be trusted.  Last resort, exact by construction: every tuple
     // through the reference arithmetic (tens of milliseconds for this voxel).

@@ -58,7 +58,7 @@ int mfx_prof_end(hipStream_t st) {
   T.ev_valid = true;
   return MFX_OK;
 }
-__global__ void mfx_fb_add_kernel(const int* __restrict__ cnt, int n, int* __restrict__ tot) {
+__global__ void mfx_fb_add_kernel(const int* __restrict__ cnt, int n, int* __restrict__ tot) {   // tot: already offset
   if (threadIdx.x < n) atomicAdd(&tot[threadIdx.x], cnt[threadIdx.x]);
 }
 static int fb_setup() {
@@ -67,30 +67,31 @@ static int fb_setup() {
   HIPCHK(hipGetDevice(&dev));
   if (T.fb_dev && T.fb_device == dev) return MFX_OK;
   if (T.fb_dev) { (void)hipFree(T.fb_dev); T.fb_dev = nullptr; }
-  HIPCHK(hipMalloc((void**)&T.fb_dev, 4 * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&T.fb_dev, 8 * sizeof(int)));
   T.fb_device = dev;
   if (!T.fb_host) {
-    HIPCHK(hipHostMalloc((void**)&T.fb_host, 4 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&T.fb_host, 8 * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&T.fb_event, hipEventDisableTiming));
   }
   return MFX_OK;
 }
 int mfx_fb_begin(hipStream_t st) {
   if (int rc = fb_setup()) return rc;
-  HIPCHK(hipMemsetAsync(mfx_thread().fb_dev, 0, 4 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(mfx_thread().fb_dev, 0, 8 * sizeof(int), st));
   return MFX_OK;
 }
-int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st) {
+int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st, int offset) {
   MfxThread& T = mfx_thread();
   if (!T.fb_dev) return MFX_OK;   // (a launcher used outside mfx_fit_batch*: nothing to report to)
-  hipLaunchKernelGGL(mfx_fb_add_kernel, dim3(1), dim3(64), 0, st, d_counters, n < 4 ? n : 4, T.fb_dev);
+  if (offset < 0 || offset + n > 8) return fail(MFX_ERR_ARG, "counter range");
+  hipLaunchKernelGGL(mfx_fb_add_kernel, dim3(1), dim3(64), 0, st, d_counters, n, T.fb_dev + offset);
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }
 int mfx_fb_end(hipStream_t st) {
   MfxThread& T = mfx_thread();
   if (!T.fb_dev) return MFX_OK;
-  HIPCHK(hipMemcpyAsync(T.fb_host, T.fb_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(T.fb_host, T.fb_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(T.fb_event, st));
   T.fb_pending = true;
   return MFX_OK;
@@ -120,9 +121,10 @@ extern "C" double mfx_last_kernel_ms(void) {
 }
 extern "C" int mfx_debug_last_fallback_count(void) { return fb_read(0); }
 extern "C" int mfx_debug_last_guard_count(void) { return fb_read(1); }
-extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < 4) ? fb_read(which) : -1; }
+extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < 8) ? fb_read(which) : -1; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { mfx_thread().k2_screen = enabled ? 1 : 0; }
 extern "C" void mfx_debug_set_k2_wide(int mode) { mfx_thread().k2_wide = mode == 1 ? 1 : (mode == 0 ? 0 : 2); }
+extern "C" void mfx_debug_set_k2x_screen(int on) { mfx_thread().k2x_screen = on ? 1 : 0; }
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (unsigned long long*)dev_ptr; }
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
 extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }

@@ -30,11 +30,12 @@ struct MfxThread {
   int k2s_nb = 0;          // 0: as many chunk images as fit; 2: force the two-image schedule
   int k2s_cap = 0;         // 0: MFX_S_CAP
   int k2_screen = -1;      // MFX_K2_SCREEN=0 disables the screening kernels
+  int k2x_screen = -1;     // MFX_K2X_SCREEN=0: the [N, N, 1] class stays on the FP64 kernel (no screening pipeline)
   int k2_wide = -1;        // MFX_K2_WIDE: 1 forces the wide screening kernel (fit_k2w.hip) wherever it applies, 0 never uses it
   // hand-back counters of the last mfx_fit_batch* call: summed on the device over its launches, copied to pinned memory
   // behind the kernels and read only when somebody asks (mfx_debug_last_*_count): the _dev entry points never synchronise
-  int* fb_dev = nullptr;           // device [4]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
-  int* fb_host = nullptr;          // pinned [4]
+  int* fb_dev = nullptr;           // device [8]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
+  int* fb_host = nullptr;          // pinned [8]
   int fb_device = -1;              // device fb_dev lives on
   hipEvent_t fb_event = nullptr;
   bool fb_pending = false;
@@ -94,7 +95,7 @@ int mfx_prof_end(hipStream_t st);
 // hand-back counters: zero the call's totals / add one launch's device counters [n <= 4 ints] / queue their copy to
 // pinned memory, all in stream order behind the work on `st` (no host synchronisation)
 int mfx_fb_begin(hipStream_t st);
-int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st);
+int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st, int offset = 0);
 int mfx_fb_end(hipStream_t st);
 
 // ---- kernel launchers, one translation unit each
@@ -109,6 +110,8 @@ int mfx_launch_k2s_ks8(const FitK2Args& a, int nvox, hipStream_t st, bool br, in
 int mfx_launch_k2s_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
 int mfx_launch_k2s_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
 // wide screening kernel (tu_k2w_*.hip): one wave per SIMD, TL row tiles per wave (fit_k2w.hip)
+size_t mfx_k2sx_lds_bytes(int KS, int N, bool bracket, int NB);
+int mfx_launch_k2sx_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL);
 int mfx_launch_k2w_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2w_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br);

@@ -2,6 +2,9 @@
 #include "mfx_host.h"
 
 #include <algorithm>
+#include <cstdlib>
+
+#define MFX_XLCAP 256   // short-list entries per voxel handed from the screening kernel to the exact stage (list mode)
 
 static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf, int ntup, int M, int NX) {
   const size_t MP = (size_t)ksteps * 4;
@@ -46,9 +49,81 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
   return mfx_fb_accumulate(cnt.as<int>(), 4, st);
 }
 
+// ---- [N, N, 1] (two fascicles + CSF) with 129..200 measurements: screening pipeline.  Per chunk of voxels:
+//   1. the screening kernel in its XC form (fit_k2s.hip; split-FP16 MFMA, relaxed bound with x unconstrained) writes
+//      every voxel's short list of atom pairs (or hands the voxel back: ring overflow, an atom inside span(x));
+//   2. this file's kernel in LIST mode (statistics, families, exact stage - no pair scan) decides the voxel from the
+//      list; a listed pair that beats its own bound by more than the margin hands the voxel back as well;
+//   3. after the last chunk the plain kernel redoes the handed-back voxels from the device-side list (no host read).
+// MFX_K2X_SCREEN=0 keeps every voxel on the plain kernel.
+template <bool BRACKET>
+static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  constexpr int KSTEPS = 50, NW = 8, NBUF = 2;
+  const int ntup = 1;
+  size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, a.P.M, a.X.NX);
+  a.xx_in_lds = 1;
+  if (lds > 160 * 1024) { lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, 0, 0); a.xx_in_lds = 0; }
+  if (lds > 160 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
+  auto kern_list = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF, true>;
+  auto kern_full = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF, false>;
+  HIPCHK(hipFuncSetAttribute((const void*)kern_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute((const void*)kern_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int chunk = 2048, cap = MFX_XLCAP;
+  const int nc = std::min(chunk, nvox);
+  const size_t slab = (size_t)2 * a.T.ldn * (MFX_XS + 2 * (ntup + 1));
+  StreamMem ws(st), cnt(st), fbm(st), xlc(st), xln(st), xlm(st);
+  HIPCHK(ws.alloc(sizeof(double) * slab * nc));
+  HIPCHK(cnt.alloc(4 * sizeof(int)));
+  HIPCHK(fbm.alloc(sizeof(int) * ((size_t)nvox + 4)));   // [0] voxels handed back, [1] of them by the bound check, [4..] their list
+  HIPCHK(xlc.alloc(sizeof(Cand) * (size_t)nc * cap));
+  HIPCHK(xln.alloc(sizeof(int) * nc));
+  HIPCHK(xlm.alloc(sizeof(double) * nc));
+  HIPCHK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(fbm.p, 0, 4 * sizeof(int), st));
+  int* fb = fbm.as<int>();
+  a.ws = ws.as<double>();
+  a.maxc = T.k2x_maxc;
+  a.stamps = T.stamps;
+  a.ovf_count = cnt.as<int>();
+  a.xl_cand = xlc.as<Cand>(); a.xl_cnt = xln.as<int>(); a.xl_mrg = xlm.as<double>(); a.xl_cap = cap;
+  a.fb_count = fb; a.fb_list = fb + 4; a.list_count = nullptr;
+  FitK2Args s{};
+  s.T = a.T; s.P = a.P; s.Y = a.Y; s.peaks = a.peaks; s.peaks_ld = a.peaks_ld; s.vox_list = a.vox_list; s.list_count = nullptr;
+  s.params = a.params; s.num_params = a.num_params; s.maxfasc = a.maxfasc; s.csf_on = a.csf_on; s.ear_on = a.ear_on;
+  s.stamps = nullptr; s.fb_count = fb; s.fb_list = fb + 4; s.maxc = 0; s.scap = T.k2s_cap ? T.k2s_cap : MFX_S_CAP;
+  s.xc = a.X.x; s.xl_cand = xlc.as<Cand>(); s.xl_cnt = xln.as<int>(); s.xl_mrg = xlm.as<double>(); s.xl_cap = cap;
+  if (int rc = mfx_prof_begin(st)) return rc;
+  for (int base = 0; base < nvox; base += chunk) {
+    const int n = std::min(chunk, nvox - base);
+    s.vox_base = base;
+    if (int rc = mfx_launch_k2sx_ks13(s, n, st, BRACKET)) return rc;
+    a.vox_base = base;
+    hipLaunchKernelGGL(kern_list, dim3(n), dim3(NW * 64), lds, st, a);
+  }
+  // the handed-back voxels, plain kernel over the device-side list (blocks beyond its length exit at once)
+  FitK2XArgs b = a;
+  b.vox_list = fb + 4; b.list_count = fb; b.xl_cand = nullptr; b.xl_cnt = nullptr;
+  for (int base = 0; base < nvox; base += chunk) {
+    b.vox_base = base;
+    hipLaunchKernelGGL(kern_full, dim3(std::min(chunk, nvox - base)), dim3(NW * 64), lds, st, b);
+  }
+  HIPCHK(hipGetLastError());
+  if (int rc = mfx_prof_end(st)) return rc;
+  if (int rc = mfx_fb_accumulate(fb, 2, st, 4)) return rc;   // counters [4], [5]: voxels handed to the plain kernel, of them by the bound check
+  return mfx_fb_accumulate(cnt.as<int>(), 4, st);
+}
+
 int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
   const int M = a.P.M;
   const bool br = a.P.any_bracket != 0;
+  {
+    MfxThread& T = mfx_thread();
+    if (T.k2x_screen < 0) { const char* e = getenv("MFX_K2X_SCREEN"); T.k2x_screen = (e && e[0] == '0') ? 0 : 1; }
+    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M > 128 && M <= 200 &&
+        mfx_k2sx_lds_bytes(13, a.T.N, br, 2) <= 160 * 1024)
+      return br ? launch_k2sx_pipeline<true>(a, nvox, st) : launch_k2sx_pipeline<false>(a, nvox, st);
+  }
   if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
   if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
   if (M <= 400) return br ? launch_k2x_t<100, true, 4, 1>(a, nvox, st) : launch_k2x_t<100, false, 4, 1>(a, nvox, st);

@@ -631,3 +631,53 @@ def test_c5_full_size_properties():
                         alt = np.array(base).copy()
                         alt[k] = (alt[k] + dlt) % N
                         assert res <= objective(v, alt)[0] * (1 + 1e-12), (v, base, k, dlt)
+
+
+def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
+    """[782, 782, 1] (two fascicles + CSF) at BASELINE config 2's size through the screening pipeline (split-FP16 screening
+    kernel with the CSF column projected out -> per-voxel short lists -> exact stage in list mode -> plain kernel for the
+    handed-back voxels): 6 144 voxels - generic mixtures, weak / absent CSF signal, one fascicle + CSF, pure CSF, 3 degree
+    crossings, identical peaks, noise-free - must equal the plain FP64 kernel of the class bit for bit, and the oracle on a
+    sample; most voxels must be decided by the pipeline itself and the bound check must never fire."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from oracle import oracle as orc
+    N, V = 782, 6144
+    sch, ms, sig_csf, _, rng = _c4_model(N, 4)
+    plan = ms.plan_for(sch)
+    M = plan.M
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(3), V)              # f0, f1, csf
+    kind = np.arange(V) % 12
+    nu[kind == 0, 2] *= 0.02                       # weak CSF signal
+    nu[kind == 1, 2] = 0                           # none, although the column is offered
+    nu[kind == 2, 1] = 0                           # fascicle 0 + CSF
+    nu[kind == 3, 0] = 0                           # fascicle 1 + CSF
+    nu[kind == 4] = [0, 0, 1]                      # pure CSF
+    p2[kind == 5] = _second_peak(rng, p1[kind == 5], 3.0)
+    p2[kind == 6] = p1[kind == 6]                  # identical peaks
+    nu /= nu.sum(1, keepdims=True)
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:2] * _rotate_cols(plan, p2, atoms[:, 1]) + nu[:, 2:3] * sig_csf)
+    noise = rng.normal(0, 500.0 / 30.0, (V, M))
+    noise[kind == 7] = 0.0                         # noise-free
+    noise[kind == 8] *= 3.0                        # SNR 10
+    Y = Y + noise
+    peaks = np.concatenate([p1, p2], axis=1)
+    one, zero = np.ones(V, bool), np.zeros(V, bool)
+    lib = L.lib()
+    args = (plan, Y, np.full(V, 2), one, zero, peaks, 2, True, False, sig_csf, None, 0)
+    got = engine.fit_batch(*args)
+    cn = [lib.mfx_debug_last_counter(q) for q in range(6)]
+    lib.mfx_debug_set_k2x_screen(0)
+    try:
+        plain = engine.fit_batch(*args)
+    finally:
+        lib.mfx_debug_set_k2x_screen(1)
+    assert np.array_equal(got, plain), "rows differ: %s" % np.flatnonzero(np.any(got != plain, axis=1))[:10]
+    assert cn[5] == 0, "bound check fired for %d voxels" % cn[5]
+    assert cn[4] <= 0.35 * V, "%d of %d voxels handed back to the plain kernel" % (cn[4], V)
+    ns = 384
+    ref = orc.fit_batch(_tables(ms), sch, Y[:ns], np.full(ns, 2), one[:ns], zero[:ns], peaks[:ns], 2, True, False, sig_csf, None, 0,
+                        nthreads=NTHREADS)
+    _assert_rows(got[:ns], ref, 2, "[782,782,1] screening pipeline", rtol=1e-9)

@@ -40,7 +40,7 @@ def run(name, cfg, V, K, c, e, E=10, N=None, bracket=False):
         L.check(lib.mfx_fit_batch_dev(plan.handle(), dY.data_ptr(), dpk.data_ptr(), K, c, e, dcsf.data_ptr() if c else None,
                                       dear.data_ptr() if e else None, E if e else 0, V, out.data_ptr(), st))
         torch.cuda.synchronize(); t1 = time.time()
-    cn = [lib.mfx_debug_last_counter(q) for q in range(4)]
+    cn = [lib.mfx_debug_last_counter(q) for q in range(6)]
     print("%-44s V=%6d N=%4d M=%3d: %8.2f ms -> %10.0f voxels/s   counters %s" % (name, V, Na, M, (t1 - t0) * 1e3, V / (t1 - t0), cn), flush=True)
 
 if not os.environ.get("MFX_DEV_K2X_ONLY"):
