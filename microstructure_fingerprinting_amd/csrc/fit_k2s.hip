@@ -664,7 +664,24 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
               const double q2 = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
               feas = hit && (fma(-e2, q2, fma(-e1, q1, yx * den)) >= 8.0 * etol);
             }
-            const double smax = mfx_wave_max_down(feas ? S : 0.0);
+            double sraise = feas ? S : 0.0;
+            if constexpr (XC) {
+              // x would get a negative weight: the pair's PLAIN two-atom score (x left out) is feasible and raises the
+              // threshold instead - without it a voxel with no x signal never leaves the single-atom threshold, floods
+              // the ring and ends up on the FP64 kernel.  Unprojected statistics from the projected ones:
+              // |d|^2 = |d'|^2 + u^2, d.y = z' |d'| + u yx, d1.d2 = d1'.d2' + u1 u2; scores here are minus yx^2.
+              if (__any(hit && !feas)) {
+                const double n1p = (double)s_cs[i], u1 = (double)s_uf[i], u2 = (double)s_uf[NP + j];
+                const double m1 = fma(u1, u1, n1p * n1p), m2 = fma(u2, u2, n2d * n2d);
+                const double i1 = mfx_rcp_nr(fmax(sqrt(m1), 1e-300)), i2 = mfx_rcp_nr(fmax(sqrt(m2), 1e-300));
+                const double w1 = fma(u1, yx, z1 * n1p) * i1, w2 = fma(u2, yx, z2 * n2d) * i2;   // d.y / |d|
+                const double c0 = fma(u1, u2, (double)acc[g]) * i1 * i2;
+                const double f1 = fma(-c0, w2, w1), f2 = fma(-c0, w1, w2), den0 = fma(-c0, c0, 1.0);
+                const bool ok0 = hit && !feas && (f1 > etol) && (f2 > etol) && (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
+                if (ok0) sraise = fma(w2, f2, w1 * f1) * mfx_rcp_nr(den0) - yx * yx;
+              }
+            }
+            const double smax = mfx_wave_max_down(fmax(sraise, 0.0));
             if (smax - 2.0 * mrg > thr) {
               thr = smax - 2.0 * mrg;
               if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));

@@ -428,6 +428,11 @@ size_t mfx_k2s_lds_bytes(int KS, int N, bool bracket, int NB) {
          (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 
+size_t mfx_k2sx_lds_bytes(int KS, int N, bool bracket, int NB) {   // + x^ [MP] and u [2][NP] (FP32)
+  const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
+  return mfx_k2s_lds_bytes(KS, N, bracket, NB) + 4 * MP + 8 * NP;
+}
+
 size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL) {
   const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
   return (size_t)2 * NB * KS * 512 * 2 + 8 * (MP + 2 * MP + 32) + sizeof(Cand) * MFX_S_CAP + 16 + 4 * (2 * MP + 4) + 4 * (2 * MP) + 4 * (4 * NP) + 4 * MP +

@@ -56,10 +56,10 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
 //      list; a listed pair that beats its own bound by more than the margin hands the voxel back as well;
 //   3. after the last chunk the plain kernel redoes the handed-back voxels from the device-side list (no host read).
 // MFX_K2X_SCREEN=0 keeps every voxel on the plain kernel.
-template <bool BRACKET>
+template <int KSTEPS, bool BRACKET>
 static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   MfxThread& T = mfx_thread();
-  constexpr int KSTEPS = 50, NW = 8, NBUF = 2;
+  constexpr int NW = 8, NBUF = 2;
   const int ntup = 1;
   size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, a.P.M, a.X.NX);
   a.xx_in_lds = 1;
@@ -97,7 +97,8 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   for (int base = 0; base < nvox; base += chunk) {
     const int n = std::min(chunk, nvox - base);
     s.vox_base = base;
-    if (int rc = mfx_launch_k2sx_ks13(s, n, st, BRACKET)) return rc;
+    const int M = a.P.M;
+    if (int rc = (M < 64 ? mfx_launch_k2sx_ks4 : (M < 128 ? mfx_launch_k2sx_ks8 : mfx_launch_k2sx_ks13))(s, n, st, BRACKET)) return rc;
     a.vox_base = base;
     hipLaunchKernelGGL(kern_list, dim3(n), dim3(NW * 64), lds, st, a);
   }
@@ -120,9 +121,13 @@ int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
   {
     MfxThread& T = mfx_thread();
     if (T.k2x_screen < 0) { const char* e = getenv("MFX_K2X_SCREEN"); T.k2x_screen = (e && e[0] == '0') ? 0 : 1; }
-    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M > 128 && M <= 200 &&
-        mfx_k2sx_lds_bytes(13, a.T.N, br, 2) <= 160 * 1024)
-      return br ? launch_k2sx_pipeline<true>(a, nvox, st) : launch_k2sx_pipeline<false>(a, nvox, st);
+    // (M must leave one padded row of the screening kernel's 16 KS rows free: not 64 or 128)
+    const int ksx = M < 64 ? 4 : (M < 128 ? 8 : 13);
+    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M <= 200 && M != 64 && M != 128 &&
+        mfx_k2sx_lds_bytes(ksx, a.T.N, br, 2) <= 160 * 1024) {
+      if (M <= 64) return br ? launch_k2sx_pipeline<16, true>(a, nvox, st) : launch_k2sx_pipeline<16, false>(a, nvox, st);
+      return br ? launch_k2sx_pipeline<50, true>(a, nvox, st) : launch_k2sx_pipeline<50, false>(a, nvox, st);
+    }
   }
   if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
   if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);

@@ -675,6 +675,7 @@ def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     finally:
         lib.mfx_debug_set_k2x_screen(1)
     assert np.array_equal(got, plain), "rows differ: %s" % np.flatnonzero(np.any(got != plain, axis=1))[:10]
+    print("[782,782,1] screening pipeline: %d of %d voxels handed to the plain kernel, %d listed pairs, %d family items" % (cn[4], V, cn[2], cn[3]))
     assert cn[5] == 0, "bound check fired for %d voxels" % cn[5]
     assert cn[4] <= 0.35 * V, "%d of %d voxels handed back to the plain kernel" % (cn[4], V)
     ns = 384
