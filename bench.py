@@ -13,7 +13,7 @@ builds the dictionary tables and broadcasts them once over RCCL.
         --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
 
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries, measured in the same process over a few
-steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4, 1 and 5 (`c4`, `c1`, `c5`), the
+steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4, 1 and 5 (`c4`, `c1`, `c5`), the two-fascicle + CSF class (`k2_csf`), the
 PCIe-inclusive rate of the host entry point (`host_api`) and the CPU baseline on all host cores.
 """
 import argparse
@@ -308,6 +308,24 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
                  "value": round(V4 / dt, 1), "unit": "voxels/s", "kernel": "mfx_fit_k2x_kernel<50,false,8,2>", "bound": "valu_f64",
                  "flop_per_voxel": FLOP_PER_VOXEL_C4, "achieved_TFLOPs": round(ach, 2), "peak_TFLOPs": PEAK_FP64_VALU_TFLOPS,
                  "frac": round(ach / PEAK_FP64_VALU_TFLOPS, 4), "exhaustive_pass_voxels": int(lib.mfx_debug_last_fallback_count())}
+    # ---- two fascicles + CSF, sub-dictionaries [782, 782, 1]: the screening pipeline (fit_k2s.hip in its XC form -> short
+    # lists -> fit_k2x.hip's exact stage; handed-back voxels on the FP64 kernel of the class), checked against that kernel
+    _, d_pk3, d_Y3 = synth_voxels(plan, V4, N, M, dev, 3, K=2, extra_cols=sig_csf[:, None])
+    o3 = torch.zeros((V4, engine.num_params(2, True, False)), dtype=torch.float64, device=dev)
+    run3 = lambda: L.check(lib.mfx_fit_batch_dev(plan.handle(), d_Y3.data_ptr(), d_pk3.data_ptr(), 2, 1, 0, d_csf.data_ptr(), None, 0, V4,
+                                                 o3.data_ptr(), st))
+    dt, kms = timed(run3, 3, 1, dev, lib)
+    handed = int(lib.mfx_debug_last_counter(4))
+    ref3 = o3.clone()
+    lib.mfx_debug_set_k2x_screen(0)
+    try:
+        dt_plain, _ = timed(run3, 1, 0, dev, lib)
+    finally:
+        lib.mfx_debug_set_k2x_screen(1)
+    out["k2_csf"] = {"workload": "%d voxels, 2 fascicles + CSF, sub-dictionaries [782, 782, 1], %d measurements" % (V4, M),
+                     "value": round(V4 / dt, 1), "unit": "voxels/s", "kernel": "mfx_fit_k2s_kernel<13,false,3,true> + mfx_fit_k2x_kernel<50,false,8,2,true>",
+                     "handed_to_fp64_kernel": handed, "fp64_kernel_value": round(V4 / dt_plain, 1),
+                     "outputs_identical_to_fp64_kernel": bool(torch.equal(o3, ref3))}
     # ---- config 1: 1 000 voxels, one fascicle, 100 atoms x 60 measurements (the reference's CPU-runnable plumbing case)
     sch1, dic1, _ = synth.make_model("C1")
     ms1 = mfu.init_PGSE_multishell_interp(dic1, sch1, np.array([0.0, 0.0, 1.0]))
