@@ -220,7 +220,7 @@ def main():
                 # peak of the type the dominant kernel multiplies in (FP16).  exec_*: what the matrix pipe really did.
                 roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_from": tfrom,
-                        "kernel": "mfx_fit_k2s_kernel<13, false, 3>", "kernel_ms": round(kavg, 3),
+                        "kernel": "mfx_fit_k2s_kernel<13, false, 3, false>", "kernel_ms": round(kavg, 3),
                         "flop_per_voxel": FLOP_PER_VOXEL,
                         "exec_f16_mfma_tflops": round(EXEC_F16_FLOP_PER_VOXEL * V / (kavg * 1e-3) / 1e12, 1),
                         "exec_f16_mfma_frac": round(EXEC_F16_FLOP_PER_VOXEL * V / (kavg * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
