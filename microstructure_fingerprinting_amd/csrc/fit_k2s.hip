@@ -387,7 +387,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   }
   const double ramp = mfx_readlane_f64(ramp_v, 0);
   const double dc_eff = XC ? MFX_S_DC * ramp : MFX_S_DC;                 // bound on |c~ - c| in the units of the test
-  const double mrg = mfx_readlane_f64(dc_eff * y_sq_p, 0);        // |S(c~) - S(c)| <= mrg
+  // (XC: never below the exact kernel's own tie tolerance, 1e-9 |y|^2: what it would treat as a tie must reach its list)
+  const double mrg = mfx_readlane_f64(XC ? fmax(dc_eff * y_sq_p, 1e-9 * y_sq) : dc_eff * y_sq_p, 0);        // |S(c~) - S(c)| <= mrg
   const double etol = mfx_readlane_f64(dc_eff * sqrt(y_sq_p), 0); // |e(c~) - e(c)| <= etol
   {
     double* s_bs = s_red;            // [2][8]
@@ -1010,9 +1011,41 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     for (int e = tid; e < neval; e += WG) {
       Cand c = s_cand[s_evl[e]];
       c.score += yx * yx;
+      c.j &= ~MFX_S_BOUND;
       dst[e] = c;
     }
-    if (tid == 0) { a.xl_cnt[blockIdx.x] = neval; a.xl_mrg[blockIdx.x] = mrg; }
+    // single atoms whose best support with ONE fascicle atom ({d} or {d, x}) could tie with the optimum (the exact
+    // kernel's family rule needs them; it computes their statistics itself): approximate scores from the projected
+    // statistics, |d|^2 = |d'|^2 + u^2, d.y = z' |d'| + u yx, everything in projected units (minus yx^2)
+    __syncthreads();   // s_cnt[2] == neval has been read by everybody
+    const double tcut = thr_fin - 2.0 * mrg;
+    for (int q = tid; q < 2 * NP; q += WG) {
+      const int k = q >= NP, n = q - k * NP;
+      const double npr = (double)s_cs[q];
+      if (n < N && npr > 0.0) {
+        const double zp = (double)s_Zf[q], u = (double)s_uf[q];
+        const double ayv = fma(u, yx, zp * npr);
+        double s1 = (ayv > 0.0 ? ayv * ayv / fma(u, u, npr * npr) : 0.0) - yx * yx;
+        // ({d, x}: whether d's weight is positive is decided by the exact kernel - a z' within the statistics' error of
+        // zero, every atom of a voxel whose signal is all x, counts as positive here)
+        if (zp > -sqrt(mrg)) s1 = fmax(s1, zp > 0.0 ? zp * zp : 0.0);
+        if (s1 >= tcut) {
+          const int slot = atomicAdd(&s_cnt[2], 1);
+          if (slot < a.xl_cap) { Cand c; c.score = s1 + yx * yx; c.i = k ? -1 : n; c.j = k ? n : -1; dst[slot] = c; }
+        }
+      }
+    }
+    __syncthreads();
+    const int nall = s_cnt[2];
+    if (nall > a.xl_cap) {
+      if (tid == 0) {
+        const int slot = atomicAdd(a.fb_count, 1);
+        a.fb_list[slot] = vox;
+        a.xl_cnt[blockIdx.x] = -1;
+      }
+      return;
+    }
+    if (tid == 0) { a.xl_cnt[blockIdx.x] = nall; a.xl_mrg[blockIdx.x] = mrg; }
     return;
   }
   if (tid == 0) {    // mf_utils.py:327, 382: start from min_obj = y_sq at pair (0,0) with w = 0, strict '<'

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       const int m = 4 * kk + lg;
       afx[kk] = (m < M) ? (lc < NX ? xx[(size_t)m * NX + lc] : (lc == NX ? s_y[m] : 0.0)) : 0.0;
     }
-    for (int tile = wave; tile < 2 * ntiles; tile += NW) {
+    // (list mode: no statistics pass - the screening kernel lists the single atoms that matter, see below)
+    for (int tile = wave; tile < (LIST ? 0 : 2 * ntiles); tile += NW) {
       const int k = tile >= ntiles, n0t = (tile - k * ntiles) * 16;
       const int n = n0t + lc;
       double bfr[KSTEPS];
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       }
     }
     __syncthreads();   // statistics and slab complete (workgroup scope)
-    for (int col = tid; col < 2 * NP; col += WG) {
+    for (int col = tid; col < (LIST ? 0 : 2 * NP); col += WG) {
       const int k = col >= NP, n = col - k * NP;
       if (n < N) {
         const double* axp = wsA + (size_t)col * MFX_XS;
@@ -648,10 +649,37 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   }
 
   MFX_STAMP(6);
+  // list mode: |d|^2, d.y and the inner products with the extra columns of ONE rotated atom, summed on demand
+  auto single_stats = [&](int k, int n, double& a2, double& ay, double* ax) {
+    a2 = 0.0; ay = 0.0;
+    for (int e = 0; e < MFX_XS; ++e) ax[e] = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double d = elem(k, m, n);
+      a2 = fma(d, d, a2);
+      ay = fma(s_y[m], d, ay);
+      for (int e = 0; e < NX; ++e) ax[e] = fma(d, xx[(size_t)m * NX + e], ax[e]);
+    }
+  };
   // ---- one-atom and no-atom supports within rounding distance of the optimum -> family items
   auto family_detection = [&]() {
   const double thr_final = gmax_run - eps_abs;
-  for (int col = tid; col < 2 * NP; col += WG) {
+  if constexpr (LIST) {   // only the single atoms the screening kernel listed can be that close
+    const int cnt = a.xl_cnt[blockIdx.x];
+    const Cand* lst = a.xl_cand + (size_t)blockIdx.x * a.xl_cap;
+    for (int q = tid; q < cnt; q += WG) {
+      const Cand e = lst[q];
+      if (e.i >= 0 && e.j >= 0) continue;
+      const int k = e.i < 0, n = k ? e.j : e.i;
+      double a2, ay, ax[MFX_XS];
+      single_stats(k, n, a2, ay, ax);
+      for (int t = 0; t < ntup; ++t)
+        if (atom_best(a2, ay, ax, t) >= thr_final) {
+          const int f = atomicAdd(&s_cnt[1], 1);
+          if (f < MFX_XFAM) { s_fam[f].type = 1 + k; s_fam[f].a = n; s_fam[f].t = t; }
+        }
+    }
+  }
+  for (int col = tid; col < (LIST ? 0 : 2 * NP); col += WG) {
     const int k = col >= NP, n = col - k * NP;
     if (n < N) {
       const double a2 = (k ? s_A22 : s_A11)[n], ay = (k ? s_Y2 : s_Y1)[n];
@@ -730,13 +758,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     const Cand* lst = a.xl_cand + (size_t)blockIdx.x * a.xl_cap;
     const double xmrg = a.xl_mrg[blockIdx.x];
     bool beaten = false;
+    double lbs = 0.0;   // best one-atom support among the listed single atoms
     for (int q = tid; q < cnt * ntup; q += WG) {
       const int c = q / ntup, t = q - c * ntup;
       const Cand e = lst[c];
-      const double r = consider(e.i, e.j & 0x3fffffff, t);
-      beaten |= (y_sq - r) > e.score + 1.25 * xmrg;
+      if (e.i >= 0 && e.j >= 0) {
+        const double r = consider(e.i, e.j & 0x3fffffff, t);
+        beaten |= (y_sq - r) > e.score + 1.25 * xmrg;
+      } else if (t == 0) {   // a single atom of dictionary 0 (j < 0) or 1 (i < 0)
+        const int k = e.i < 0, n = k ? e.j : e.i;
+        double a2, ay, ax[MFX_XS];
+        single_stats(k, n, a2, ay, ax);
+        for (int tt = 0; tt < ntup; ++tt) lbs = fmax(lbs, atom_best(a2, ay, ax, tt));
+      }
     }
-    double lb = (key >= 0) ? y_sq - res : 0.0;
+    double lb = fmax((key >= 0) ? y_sq - res : 0.0, lbs);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lb = fmax(lb, __shfl_xor(lb, o));
     if (lane == 0) s_red[wave] = lb;

@@ -121,9 +121,9 @@ int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
   {
     MfxThread& T = mfx_thread();
     if (T.k2x_screen < 0) { const char* e = getenv("MFX_K2X_SCREEN"); T.k2x_screen = (e && e[0] == '0') ? 0 : 1; }
-    // (M must leave one padded row of the screening kernel's 16 KS rows free: not 64 or 128)
+    // (the screening kernel needs one free padded row among its 16 KS: M < 64 -> 4 k-steps, M < 128 -> 8, M <= 200 -> 13)
     const int ksx = M < 64 ? 4 : (M < 128 ? 8 : 13);
-    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M <= 200 && M != 64 && M != 128 &&
+    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M <= 200 &&
         mfx_k2sx_lds_bytes(ksx, a.T.N, br, 2) <= 160 * 1024) {
       if (M <= 64) return br ? launch_k2sx_pipeline<16, true>(a, nvox, st) : launch_k2sx_pipeline<16, false>(a, nvox, st);
       return br ? launch_k2sx_pipeline<50, true>(a, nvox, st) : launch_k2sx_pipeline<50, false>(a, nvox, st);

@@ -642,7 +642,7 @@ def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     from microstructure_fingerprinting_amd import _lib as L
     from microstructure_fingerprinting_amd import engine, synth
     from oracle import oracle as orc
-    N, V = 782, 6144
+    N, V = 782, int(os.environ.get("MFX_STRESS_CSF_V", "6144"))   # (one-off deep runs: e.g. 61440)
     sch, ms, sig_csf, _, rng = _c4_model(N, 4)
     plan = ms.plan_for(sch)
     M = plan.M
