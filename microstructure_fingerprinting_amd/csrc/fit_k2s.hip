@@ -387,9 +387,12 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   }
   const double ramp = mfx_readlane_f64(ramp_v, 0);
   const double dc_eff = XC ? MFX_S_DC * ramp : MFX_S_DC;                 // bound on |c~ - c| in the units of the test
-  // (XC: never below the exact kernel's own tie tolerance, 1e-9 |y|^2: what it would treat as a tie must reach its list)
-  const double mrg = mfx_readlane_f64(XC ? fmax(dc_eff * y_sq_p, 1e-9 * y_sq) : dc_eff * y_sq_p, 0);        // |S(c~) - S(c)| <= mrg
-  const double etol = mfx_readlane_f64(dc_eff * sqrt(y_sq_p), 0); // |e(c~) - e(c)| <= etol
+  // XC: the projected statistics cancel - z' |d'| = d.y - u yx - so the FP32 rounding of table, signal and column
+  // (<= 3.6e-7 |d||y| in that difference) is no longer negligible when most of the signal is x: + 2e-6 ramp |y||y'| in a
+  // score, + 2e-6 ramp |y| in e.  And never below the exact kernel's own tie tolerance, 1e-9 |y|^2: what it would
+  // treat as a tie must reach its list.
+  const double mrg = mfx_readlane_f64(XC ? fmax(dc_eff * y_sq_p + 2e-6 * ramp * sqrt(y_sq * y_sq_p), 1e-9 * y_sq) : dc_eff * y_sq_p, 0);   // |S(c~) - S(c)| <= mrg
+  const double etol = mfx_readlane_f64(XC ? dc_eff * sqrt(y_sq_p) + 2e-6 * ramp * sqrt(y_sq) : dc_eff * sqrt(y_sq_p), 0);   // |e(c~) - e(c)| <= etol
   {
     double* s_bs = s_red;            // [2][8]
     int* s_bn = (int*)(s_red + 16);  // [2][8]
@@ -1029,9 +1032,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         // ({d, x}: whether d's weight is positive is decided by the exact kernel - a z' within the statistics' error of
         // zero, every atom of a voxel whose signal is all x, counts as positive here)
         if (zp > -sqrt(mrg)) s1 = fmax(s1, zp > 0.0 ? zp * zp : 0.0);
-        if (s1 >= tcut) {
+        // A pair whose projected two-atom solution has a non-positive weight is bounded by its better projected SINGLE
+        // atom, z'^2 (x free, even negative) - not the score of any support, so unlike section 4.1 the best single atom
+        // does not stand for such pairs: every atom whose z'^2 reaches the threshold takes ALL its pairs to the exact
+        // kernel ("forced" family: -2 instead of -1 in the list entry)
+        const bool forced = zp > 0.0 && zp * zp >= tcut;
+        if (s1 >= tcut || forced) {
           const int slot = atomicAdd(&s_cnt[2], 1);
-          if (slot < a.xl_cap) { Cand c; c.score = s1 + yx * yx; c.i = k ? -1 : n; c.j = k ? n : -1; dst[slot] = c; }
+          const int mark = forced ? -2 : -1;
+          if (slot < a.xl_cap) { Cand c; c.score = s1 + yx * yx; c.i = k ? mark : n; c.j = k ? n : mark; dst[slot] = c; }
         }
       }
     }

@@ -672,8 +672,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       const int k = e.i < 0, n = k ? e.j : e.i;
       double a2, ay, ax[MFX_XS];
       single_stats(k, n, a2, ay, ax);
+      // forced (-2): the screening kernel's bound of the atom's pairs is its relaxed single score, all of them must be seen
+      const bool forced = (k ? e.i : e.j) == -2;
       for (int t = 0; t < ntup; ++t)
-        if (atom_best(a2, ay, ax, t) >= thr_final) {
+        if (forced || atom_best(a2, ay, ax, t) >= thr_final) {
           const int f = atomicAdd(&s_cnt[1], 1);
           if (f < MFX_XFAM) { s_fam[f].type = 1 + k; s_fam[f].a = n; s_fam[f].t = t; }
         }
