@@ -145,6 +145,26 @@ static double sweep(int tiles) {
   worst = std::fmax(worst, run_family<KS>("increasing ramp", A, B, tiles).maxabs);
   fill([&](int k, int) { return (float)(128.0 * (K - k) / K); });
   worst = std::fmax(worst, run_family<KS>("decreasing ramp", A, B, tiles).maxabs);
+  // 12. the [N, N, 1] form of the screening kernel: dictionary-like vectors whose LAST row carries -u1 / u2, u = 0.8 |d|
+  // (the projected cross product d1.d2 - u1 u2 out of the same MFMAs: one product of the size of all others together,
+  // with the opposite sign).  The error is relative to the norms of the AUGMENTED vectors here: x 1.64 for |d1||d2|.
+  {
+    std::vector<double> pa((size_t)tiles * 32 * 2), pb((size_t)tiles * 32 * 2);
+    for (auto& v : pa) v = U(rng);
+    for (auto& v : pb) v = U(rng);
+    for (size_t v = 0; v < (size_t)tiles * 32; ++v) {
+      double na = 0, nb = 0;
+      for (int k = 0; k + 1 < K; ++k) {
+        const double x = 128.0 * (0.3 + 0.7 * pa[2 * v]) * std::exp(-3.0 * pa[2 * v + 1] * k / K);
+        const double y = 128.0 * (0.3 + 0.7 * pb[2 * v]) * std::exp(-3.0 * pb[2 * v + 1] * k / K);
+        A[v * K + k] = (float)x; B[v * K + k] = (float)y;
+        na += (double)(float)x * (float)x; nb += (double)(float)y * (float)y;
+      }
+      A[v * K + K - 1] = (float)(-0.8 * std::sqrt(na));
+      B[v * K + K - 1] = (float)(0.8 * std::sqrt(nb));
+    }
+    worst = std::fmax(worst, run_family<KS>("dictionary-like + spare row (-u1, u2), u = 0.8 |d|", A, B, tiles).maxabs);
+  }
   return worst;
 }
 
