@@ -49,7 +49,7 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
   return mfx_fb_accumulate(cnt.as<int>(), 4, st);
 }
 
-// ---- [N, N, 1] (two fascicles + CSF) with 129..200 measurements: screening pipeline.  Per chunk of voxels:
+// ---- [N, N, 1] (two fascicles + CSF) with up to 200 measurements: screening pipeline.  Per chunk of voxels:
 //   1. the screening kernel in its XC form (fit_k2s.hip; split-FP16 MFMA, relaxed bound with x unconstrained) writes
 //      every voxel's short list of atom pairs (or hands the voxel back: ring overflow, an atom inside span(x));
 //   2. this file's kernel in LIST mode (statistics, families, exact stage - no pair scan) decides the voxel from the
@@ -69,16 +69,18 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   auto kern_full = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF, false>;
   HIPCHK(hipFuncSetAttribute((const void*)kern_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipFuncSetAttribute((const void*)kern_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int chunk = 2048, cap = MFX_XLCAP;
-  const int nc = std::min(chunk, nvox);
+  // the screening and list-mode launches take up to 32 768 voxels at a time (4 KB of list per voxel; the list-mode
+  // kernel uses no slab), the plain kernel its usual 2 048 (256 KB of slab per workgroup)
+  const int chunk = 2048, big = 32768, cap = MFX_XLCAP;
+  const int nc = std::min(chunk, nvox), nb = std::min(big, nvox);
   const size_t slab = (size_t)2 * a.T.ldn * (MFX_XS + 2 * (ntup + 1));
   StreamMem ws(st), cnt(st), fbm(st), xlc(st), xln(st), xlm(st);
   HIPCHK(ws.alloc(sizeof(double) * slab * nc));
   HIPCHK(cnt.alloc(4 * sizeof(int)));
   HIPCHK(fbm.alloc(sizeof(int) * ((size_t)nvox + 4)));   // [0] voxels handed back, [1] of them by the bound check, [4..] their list
-  HIPCHK(xlc.alloc(sizeof(Cand) * (size_t)nc * cap));
-  HIPCHK(xln.alloc(sizeof(int) * nc));
-  HIPCHK(xlm.alloc(sizeof(double) * nc));
+  HIPCHK(xlc.alloc(sizeof(Cand) * (size_t)nb * cap));
+  HIPCHK(xln.alloc(sizeof(int) * nb));
+  HIPCHK(xlm.alloc(sizeof(double) * nb));
   HIPCHK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(fbm.p, 0, 4 * sizeof(int), st));
   int* fb = fbm.as<int>();
@@ -94,8 +96,8 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   s.stamps = nullptr; s.fb_count = fb; s.fb_list = fb + 4; s.maxc = 0; s.scap = T.k2s_cap ? T.k2s_cap : MFX_S_CAP;
   s.xc = a.X.x; s.xl_cand = xlc.as<Cand>(); s.xl_cnt = xln.as<int>(); s.xl_mrg = xlm.as<double>(); s.xl_cap = cap;
   if (int rc = mfx_prof_begin(st)) return rc;
-  for (int base = 0; base < nvox; base += chunk) {
-    const int n = std::min(chunk, nvox - base);
+  for (int base = 0; base < nvox; base += big) {
+    const int n = std::min(big, nvox - base);
     s.vox_base = base;
     const int M = a.P.M;
     if (int rc = (M < 64 ? mfx_launch_k2sx_ks4 : (M < 128 ? mfx_launch_k2sx_ks8 : mfx_launch_k2sx_ks13))(s, n, st, BRACKET)) return rc;
