@@ -111,7 +111,6 @@ int mfx_launch_k2s_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br, i
 int mfx_launch_k2s_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br, int NB);
 // wide screening kernel (tu_k2w_*.hip): one wave per SIMD, TL row tiles per wave (fit_k2w.hip)
 size_t mfx_k2sx_lds_bytes(int KS, int N, bool bracket, int NB);
-int mfx_launch_k2sx_ks4(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2sx_ks8(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2sx_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL);
