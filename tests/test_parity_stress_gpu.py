@@ -682,3 +682,43 @@ def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     ref = orc.fit_batch(_tables(ms), sch, Y[:ns], np.full(ns, 2), one[:ns], zero[:ns], peaks[:ns], 2, True, False, sig_csf, None, 0,
                         nthreads=NTHREADS)
     _assert_rows(got[:ns], ref, 2, "[782,782,1] screening pipeline", rtol=1e-9)
+
+
+def test_mixed_classes_full_size_vs_oracle():
+    """A mixed ROI at BASELINE config 2's size (782 atoms x 200 measurements) through the host entry point: voxels with 0, 1
+    or 2 fascicles, with and without the CSF flag, interleaved - every class goes through its own kernel from per-chunk
+    voxel lists (the two-fascicle + CSF class through the screening pipeline with a voxel list) and must equal the oracle
+    row by row."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from oracle import oracle as orc
+    N, V = 782, 720
+    sch, ms, sig_csf, _, rng = _c4_model(N, 4)
+    plan = ms.plan_for(sch)
+    M = plan.M
+    K = rng.integers(0, 3, V)
+    csf = rng.random(V) < 0.5
+    csf[K == 0] = True                              # (K = 0 without CSF: nothing to estimate, rows stay zero)
+    csf[::17] = False
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(3), V)
+    nu[K < 2, 1] = 0
+    nu[K < 1, 0] = 0
+    nu[~csf, 2] = 0
+    nu[nu.sum(1) == 0] = [0, 0, 1]
+    nu /= nu.sum(1, keepdims=True)
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:2] * _rotate_cols(plan, p2, atoms[:, 1]) + nu[:, 2:3] * sig_csf)
+    Y = Y + rng.normal(0, 500.0 / 30.0, (V, M))
+    peaks = np.concatenate([p1, p2], axis=1)
+    zero = np.zeros(V, bool)
+    got = engine.fit_batch(plan, Y, K, csf, zero, peaks, 2, True, False, sig_csf, None, 0)
+    cn = [L.lib().mfx_debug_last_counter(q) for q in range(6)]
+    ref = orc.fit_batch(_tables(ms), sch, Y, K, csf, zero, peaks, 2, True, False, sig_csf, None, 0, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "mixed ROI at 782 x 200", rtol=1e-9)
+    assert cn[5] == 0
+    # the same rows through the reference's ROI gather (rows argument): the volume holds every voxel twice
+    vol = np.concatenate([Y[::-1], Y], axis=0)
+    rows = (V + np.arange(V)).astype(np.int64)
+    got2 = engine.fit_batch(plan, vol, K, csf, zero, peaks, 2, True, False, sig_csf, None, 0, rows=rows)
+    assert np.array_equal(got, got2)
