@@ -26,6 +26,10 @@
 // half-step; a last round with one row tile left is shared by all waves.  Everything that only ranks reads
 // an FP32 copy of the table, two adjacent atoms per 16-byte load (the vector-memory pipe, not the matrix
 // pipe, is what this kernel saturates next to VALU issue: DESIGN.md 4.0/4.1).
+//
+// XC = true: the same sweep for the class with one fixed extra column ([N, N, 1]: two fascicles + CSF), the column projected
+// out through a spare measurement row; it writes per-voxel short lists for fit_k2x.hip's exact stage instead of running
+// one (see the comment at the kernel and DESIGN.md 4.3b).
 #pragma once
 #include "fit_k2.hip"
 

@@ -1,4 +1,5 @@
-// fit_k2x.hip -- fused per-voxel kernel for two fascicles PLUS voxel-independent compartments:
+// fit_k2x.hip -- fused per-voxel kernel for two fascicles PLUS voxel-independent compartments (and, with LIST = true,
+// the exact stage behind the screening kernel's short lists for the [N, N, 1] class: fit_k2s.hip XC = true):
 //   [N,N,1] (CSF), [N,N,E] (EAR)          -> solve_exhaustive_posweights_3   (mf_utils.py:470-607)
 //   [N,N,1,E] (CSF + EAR)                 -> solve_exhaustive_posweights_4up (mf_utils.py:612-657)
 // Same skeleton as fit_k2.hip (one workgroup per voxel, D1 tile in registers, D2 tiles through LDS, FP64
