@@ -19,7 +19,9 @@
 
 // BR: the protocol has G-bracketed rows (screening through the plan's virtual shells, exact stage as mfx_eval_br)
 // TL: row tiles per wave; NB: LDS images of D2 chunks (2: one workgroup barrier per chunk; 1: two)
-template <int KS, int TL, bool BR, int NB>
+// XC: the [N, N, 1] form (one fixed extra column x projected out through the last padded measurement row; short lists for
+// fit_k2x.hip's exact stage instead of an exact stage here) - the same changes as in fit_k2s.hip, see there and DESIGN.md 4.3b.
+template <int KS, int TL, bool BR, int NB, bool XC = false>
 __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   constexpr int WG = 256, NW = 4;
   constexpr int MP = KS * 16;  // padded measurement count
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   const int NP = (N + 31) & ~31;  // atoms padded to a multiple of 32
   const int ntiles = NP >> 5;
   const double2* __restrict__ tab = a.T.tab;
-  const int vox = a.vox_list ? a.vox_list[blockIdx.x] : blockIdx.x;
+  const int vox = a.vox_list ? a.vox_list[a.vox_base + blockIdx.x] : a.vox_base + (int)blockIdx.x;
 
   // ---- LDS carve-up
   _Float16* sBh = (_Float16*)smem;                 // [NB][KS][64][8]  hi halves, fragment order
@@ -55,6 +57,8 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   int* s_r1 = (int*)(s_dG + (BR ? MP : 0));        // [2][MP] upper-shell knot row * ldn, or -1
   int* s_rs = BR ? s_r1 + 2 * MP : s_r0;           // [2][MP] row offsets used by the screening passes
   int* s_evl4 = s_r1 + (BR ? 4 * MP : 0);          // [MFX_S_CAP] exact-stage compaction list, KS < 8 only (else inside the B image)
+  float* s_xf = (float*)(s_evl4 + (KS < 8 ? MFX_S_CAP : 0));   // XC: [MP] the FP32 copy of x (0 beyond M)
+  float* s_uf = s_xf + (XC ? MP : 0);              // XC: [2][NP] u = d.x^ of the rotated atoms
 
   MFX_STAMP(0);
   // ---- phase 0: y, knot-interval descriptors
@@ -90,6 +94,10 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
     }
   }
   if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  if constexpr (XC) {
+    for (int m = tid; m < MP; m += WG) s_xf[m] = (m < M) ? (float)a.xc[m] : 0.0f;
+    if (tid < 2) ((unsigned long long*)s_red)[24 + tid] = 0ull;   // max |d|^2/|d'|^2 of each dictionary (bits of a non-negative double)
+  }
   if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
 
@@ -121,8 +129,15 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   for (int m = 0; m < M; ++m) y_sq_v += s_y[m] * s_y[m];
   // wave-uniform values that live through the whole kernel go to scalar registers (the vector file is full)
   const double y_sq = mfx_readlane_f64(y_sq_v, 0);
-  const double mrg = mfx_readlane_f64(MFX_S_DC * y_sq, 0);        // |S(c~) - S(c)| <= mrg
-  const double etol = mfx_readlane_f64(MFX_S_DC * sqrt(y_sq), 0); // |e(c~) - e(c)| <= etol
+  double rsh_v = 1.0, yx_v = 0.0;   // XC: 1/|v| and y.v/|v| of v = the FP32 copy of x (see fit_k2s.hip)
+  if constexpr (XC) {
+    double h = 0.0, xy = 0.0;
+    for (int m = 0; m < M; ++m) { const double xv = (double)s_xf[m]; h = fma(xv, xv, h); xy = fma(xv, (double)s_yf[m], xy); }
+    rsh_v = h > 0.0 ? 1.0 / sqrt(h) : 0.0;
+    yx_v = xy * rsh_v;
+  }
+  const double rsh = mfx_readlane_f64(rsh_v, 0), yx = mfx_readlane_f64(yx_v, 0);
+  const double y_sq_p = XC ? fmax(y_sq - yx * yx, 0.0) : y_sq;   // |y'|^2
   double my_s[2] = {0.0, 0.0};
   int my_n[2] = {0, 0};
   {
@@ -136,17 +151,22 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
     // read once for both purposes: the L2 -> L1 fill rate, ~32 B/clk, is what bounds these passes).
     const int VH = ((N + 1) / 2 + 63) & ~63;
     const int npass = (VH + WG - 1) / WG;
+#pragma unroll 1
+    for (int kd = XC ? 0 : 1; kd < 2; ++kd) {   // (XC: both dictionaries, projected statistics)
+    double ms_cur = 0.0, rm2_cur = 1.0;
+    int mn_cur = 0;
     for (int p0 = 0; p0 < npass; p0 += 2) {
       int kq[2], nq[2];
       bool wact[2];
-      double a2[2][2], ay[2][2];
+      double a2[2][2], ay[2][2], au[2][2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int v = tid + WG * (p0 + q);
-        kq[q] = 1;
+        kq[q] = kd;
         nq[q] = 2 * v;
         wact[q] = __any((p0 + q < npass) && (nq[q] < N));
         a2[q][0] = a2[q][1] = ay[q][0] = ay[q][1] = 0.0;
+        au[q][0] = au[q][1] = 0.0;
       }
       // software pipeline over groups of four rows: the 8 table loads of the next group are in flight while this
       // group is accumulated (the vector-memory pipe and the FP64 VALU work of this pass each take ~40 k cycles per
@@ -169,6 +189,8 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       auto accumulate = [&](int m4, auto stc) {
         constexpr int st = decltype(stc)::value;
         const f32x4 yv = *(const f32x4*)(s_yf + m4);
+        f32x4 xv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (XC) xv = *(const f32x4*)(s_xf + m4);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (wact[q]) {
@@ -182,6 +204,11 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
               ay[q][0] = fma(ye, d0, ay[q][0]);
               a2[q][1] = fma(d1, d1, a2[q][1]);
               ay[q][1] = fma(ye, d1, ay[q][1]);
+              if constexpr (XC) {
+                const double xe = (double)xv[e];
+                au[q][0] = fma(xe, d0, au[q][0]);
+                au[q][1] = fma(xe, d1, au[q][1]);
+              }
             }
           }
         }
@@ -200,15 +227,38 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
           const int k = kq[q], n = nq[q] + u;
           if (p0 + q < npass && n < NP) {
             const bool act = n < N;
-            const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
-            const double z = ay[q][u] * inv;
-            s_Zf[k * NP + n] = act ? (float)z : -1e30f;
-            s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
-            const double s = z > 0.0 ? z * z : 0.0;
-            if (act && s > my_s[k]) { my_s[k] = s; my_n[k] = n; }   // increasing n per thread and dictionary
+            if constexpr (!XC) {
+              const double inv = (act && a2[q][u] > 0.0) ? 1.0 / sqrt(a2[q][u]) : 0.0;
+              const double z = ay[q][u] * inv;
+              s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+              s_cs[NP + n] = (act && inv > 0.0) ? (float)sqrt(a2[q][u]) : 0.0f;
+              const double s = z > 0.0 ? z * z : 0.0;
+              if (act && s > ms_cur) { ms_cur = s; mn_cur = n; }   // increasing n per thread and dictionary
+            } else {   // projected statistics (fit_k2s.hip)
+              const double uu = au[q][u] * rsh;
+              const double n2p = a2[q][u] - uu * uu;
+              const bool ok = act && a2[q][u] > 0.0;
+              if (ok && !(n2p > a2[q][u] * (1.0 / 16.0))) s_cnt[1] = 1;
+              const bool okp = ok && n2p > 0.0;
+              const double np = okp ? sqrt(n2p) : 0.0;
+              const double inv = okp ? 1.0 / np : 0.0;
+              const double z = (ay[q][u] - uu * yx) * inv;
+              s_Zf[k * NP + n] = act ? (float)z : -1e30f;
+              s_cs[k * NP + n] = okp ? (float)np : 0.0f;
+              s_uf[k * NP + n] = okp ? (float)uu : 0.0f;
+              if (okp) rm2_cur = fmax(rm2_cur, a2[q][u] * inv * inv);
+              const bool feas = okp && z > 0.0 && (yx - z * inv * uu) >= 0.0;
+              const double s = feas ? z * z : 0.0;
+              if (s > ms_cur) { ms_cur = s; mn_cur = n; }
+            }
           }
         }
       }
+    }
+    if (kd == 0) { my_s[0] = ms_cur; my_n[0] = mn_cur; } else { my_s[1] = ms_cur; my_n[1] = mn_cur; }
+    if constexpr (XC) {
+      if (rm2_cur > 1.0) atomicMax((unsigned long long*)s_red + 24 + kd, mfx_nonneg_bits(rm2_cur));
+    }
     }
   }
   // best single atom of each dictionary (first index on ties): they stand for every pair whose optimum
@@ -218,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
     double* s_bs = s_red;            // [2][8]
     int* s_bn = (int*)(s_red + 16);  // [2][8]
 #pragma unroll
-    for (int k = 1; k < 2; ++k) {
+    for (int k = XC ? 0 : 1; k < 2; ++k) {
       double s = my_s[k];
       int n = my_n[k];
 #pragma unroll
@@ -232,9 +282,23 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       if (lane == 0) { s_bs[k * 8 + wave] = s; s_bn[k * 8 + wave] = n; }
     }
     __syncthreads();
+  }
+  // margins (XC: amplified, with the statistics' rounding term and the exact kernel's tie tolerance as floor: fit_k2s.hip)
+  double ramp_v = 1.0;
+  if constexpr (XC) {
+    const unsigned long long* rw = (const unsigned long long*)s_red + 24;
+    ramp_v = sqrt(fmax(1.0, __longlong_as_double((long long)rw[0]))) * sqrt(fmax(1.0, __longlong_as_double((long long)rw[1])));
+  }
+  const double ramp = mfx_readlane_f64(ramp_v, 0);
+  const double dc_eff = XC ? MFX_S_DC * ramp : MFX_S_DC;
+  const double mrg = mfx_readlane_f64(XC ? fmax(dc_eff * y_sq_p + 2e-6 * ramp * sqrt(y_sq * y_sq_p), 1e-9 * y_sq) : dc_eff * y_sq_p, 0);   // |S(c~) - S(c)| <= mrg
+  const double etol = mfx_readlane_f64(XC ? dc_eff * sqrt(y_sq_p) + 2e-6 * ramp * sqrt(y_sq) : dc_eff * sqrt(y_sq_p), 0);   // |e(c~) - e(c)| <= etol
+  {
+    double* s_bs = s_red;            // [2][8]
+    int* s_bn = (int*)(s_red + 16);  // [2][8]
     if (tid == 0) {
       double best1 = 0.0;
-      for (int k = 1; k < 2; ++k) {   // D1's best single atom is known after the last round (see there)
+      for (int k = XC ? 0 : 1; k < 2; ++k) {   // (!XC) D1's best single atom is known after the last round (see there)
         double s = s_bs[k * 8];
         int n = s_bn[k * 8];
         for (int w = 1; w < NW; ++w) {
@@ -243,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
           if (s2 > s || (s2 == s && n2 < n)) { s = s2; n = n2; }
         }
         best1 = fmax(best1, s);
-        if (s > 0.0) {
+        if (!XC && s > 0.0) {   // (XC: supports with fewer than two fascicle atoms belong to the exact kernel's families)
           const int slot = s_cnt[0]++;
           s_cand[slot].score = s + mrg;   // exact single-atom score up to the statistics' rounding: evaluated only if it can win
           s_cand[slot].i = k ? 0 : n;
@@ -299,6 +363,8 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       const int n = rts[t] * 32 + lr;
       const int nn = min(n, ldn - 1);
       double a2 = 0.0, ay = 0.0;
+      float um1 = 0.0f;   // XC: the last padded row of the A operand carries -u1
+      if constexpr (XC) um1 = (rt_valid && n < N) ? -s_uf[n] : 0.0f;
       mfx_static_for<0, KS>([&](auto kc) {
         constexpr int ks = decltype(kc)::value;
         float2 d[8];
@@ -309,9 +375,13 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         for (int j = 0; j < 8; ++j) {
           float fv = fmaf(d[j].y, s_t0f[16 * ks + 8 * lh + j], d[j].x);
           fv = rt_valid ? fv : 0.0f;
-          const double fd = (double)fv;
-          a2 = fma(fd, fd, a2);
-          ay = fma((double)s_yf[16 * ks + 8 * lh + j], fd, ay);
+          if constexpr (XC) {
+            if constexpr (ks == KS - 1) { if (j == 7) fv = lh ? um1 : fv; }
+          } else {
+            const double fd = (double)fv;
+            a2 = fma(fd, fd, a2);
+            ay = fma((double)s_yf[16 * ks + 8 * lh + j], fd, ay);
+          }
           _Float16 x, y;
           mfx_split16(fv, x, y);
           vh[j] = x; vl[j] = y;
@@ -319,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         asm volatile("" : "+v"(vh), "+v"(vl));
         afh[t][ks] = vh; afl[t][ks] = vl;
       });
+      if constexpr (!XC) {
       a2 += __shfl_xor(a2, 32);
       ay += __shfl_xor(ay, 32);
       const bool act = rt_valid && n < N;
@@ -343,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       nb = __builtin_amdgcn_readfirstlane(nb);
       if (sb > bs1) { bs1 = sb; bn1 = nb; }
       if (lane == 0 && sb - mrg > 0.0) atomicMax(&s_thr[0], mfx_nonneg_bits(sb - mrg));
+      }
     });
 
     // ---- pair screen of one 32x32 accumulator tile (row tile t of this wave) against column tile ct: the fast FP32
@@ -351,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
     double thr_rows[TL];
 #pragma unroll
     for (int t = 0; t < TL; ++t) thr_rows[t] = -1.0;
-    constexpr float DCF = (float)MFX_S_DC + 2e-6f;
+    const float DCF = XC ? (float)(((double)MFX_S_DC + 2e-6) * ramp) * (1.0f + 2e-7f) : (float)MFX_S_DC + 2e-6f;
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
       Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
@@ -424,11 +496,28 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
           if (hit) {
             S = num / den;
           } else if (near) {
-            const double dlo = den - 2.0 * MFX_S_DC - MFX_S_DC * MFX_S_DC;
+            const double dlo = den - 2.0 * dc_eff - dc_eff * dc_eff;
             const double u1 = fabs(e1) + etol, u2 = fabs(e2) + etol;
             S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
           }
-          const double smax = wave_max(hit ? S : 0.0);
+          double sraise = hit ? S : 0.0;
+          if constexpr (XC) {   // see fit_k2s.hip: only feasible scores raise the threshold
+            const double q1 = (double)s_uf[i] * mfx_rcp_nr(fmax((double)s_cs[i], 1e-300));
+            const double q2 = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
+            const bool feas = hit && (fma(-e2, q2, fma(-e1, q1, yx * den)) >= 8.0 * etol);
+            sraise = feas ? S : 0.0;
+            if (__any(hit && !feas)) {
+              const double n1p = (double)s_cs[i], u1 = (double)s_uf[i], u2 = (double)s_uf[NP + j];
+              const double m1 = fma(u1, u1, n1p * n1p), m2 = fma(u2, u2, n2d * n2d);
+              const double i1 = mfx_rcp_nr(fmax(sqrt(m1), 1e-300)), i2 = mfx_rcp_nr(fmax(sqrt(m2), 1e-300));
+              const double w1 = fma(u1, yx, z1 * n1p) * i1, w2 = fma(u2, yx, z2 * n2d) * i2;
+              const double c0 = fma(u1, u2, (double)acc[g]) * i1 * i2;
+              const double f1 = fma(-c0, w2, w1), f2 = fma(-c0, w1, w2), den0 = fma(-c0, c0, 1.0);
+              const bool ok0 = hit && !feas && (f1 > etol) && (f2 > etol) && (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
+              if (ok0) sraise = fma(w2, f2, w1 * f1) * mfx_rcp_nr(den0) - yx * yx;
+            }
+          }
+          const double smax = wave_max(fmax(sraise, 0.0));
           if (smax - 2.0 * mrg > thr) {
             thr = smax - 2.0 * mrg;
             if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
@@ -455,6 +544,8 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       for (int ct = wave; ct < ntiles; ct += NW) {
         const int n = ct * 32 + lr;
         const int nn = min(n, ldn - 1);
+        float tail_u2 = 0.0f;
+        if constexpr (XC) tail_u2 = s_uf[NP + n];
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
@@ -471,7 +562,9 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             _Float16 x, y;
-            mfx_split16(fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x), x, y);
+            float fv = fmaf(d[ks & 1][j].y, s_t0f[MP + 16 * ks + 8 * lh + j], d[ks & 1][j].x);
+            if constexpr (XC && ks == KS - 1) { if (j == 7) fv = lh ? tail_u2 : fv; }   // the spare row carries u2
+            mfx_split16(fv, x, y);
             bh[j] = x; bl[j] = y;
           }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[0][ks], bh, acc, 0, 0, 0);
@@ -498,7 +591,9 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
       c0 = 2 * (qq & 15);
       return ok;
     };
+    int g_ch = 0;   // chunk whose table entries gd holds (XC: the spare row needs the atoms' u2)
     auto gen_load = [&](int ch) {
+      g_ch = ch;
 #pragma unroll
       for (int it = 0; it < (NB == 2 ? IT : 0); ++it) {
         int rb, c0;
@@ -520,9 +615,13 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         _Float16 x, y;
-        mfx_split16(fmaf(gd[it][e0 + e][1], tq[e], gd[it][e0 + e][0]), x, y);
+        float v0 = fmaf(gd[it][e0 + e][1], tq[e], gd[it][e0 + e][0]), v1 = fmaf(gd[it][e0 + e][3], tq[e], gd[it][e0 + e][2]);
+        if constexpr (XC) {   // the spare row (last row of the last fragment block) carries u2 of the item's two atoms
+          if (e0 + e == 7) { const bool spare = (rb == 2 * KS - 1); v0 = spare ? s_uf[NP + g_ch * 32 + c0] : v0; v1 = spare ? s_uf[NP + g_ch * 32 + c0 + 1] : v1; }
+        }
+        mfx_split16(v0, x, y);
         g_hi0[it][e0 + e] = x; g_lo0[it][e0 + e] = y;
-        mfx_split16(fmaf(gd[it][e0 + e][3], tq[e], gd[it][e0 + e][2]), x, y);
+        mfx_split16(v1, x, y);
         g_hi1[it][e0 + e] = x; g_lo1[it][e0 + e] = y;
       }
     };
@@ -570,9 +669,13 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         for (int e = 0; e < 8; ++e) {
           const float tq = e < 4 ? ta[e & 3] : tb[e & 3];
           _Float16 x, y;
-          mfx_split16(fmaf(st[it & 1][e][1], tq, st[it & 1][e][0]), x, y);
+          float v0 = fmaf(st[it & 1][e][1], tq, st[it & 1][e][0]), v1 = fmaf(st[it & 1][e][3], tq, st[it & 1][e][2]);
+          if constexpr (XC) {
+            if (e == 7) { const bool spare = (rb == 2 * KS - 1); v0 = spare ? s_uf[NP + ch * 32 + c0] : v0; v1 = spare ? s_uf[NP + ch * 32 + c0 + 1] : v1; }
+          }
+          mfx_split16(v0, x, y);
           hi0[e] = x; lo0[e] = y;
-          mfx_split16(fmaf(st[it & 1][e][3], tq, st[it & 1][e][2]), x, y);
+          mfx_split16(v1, x, y);
           hi1[e] = x; lo1[e] = y;
         }
         if (ok) {
@@ -787,12 +890,63 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   const int ncand = nappend > a.scap ? a.scap : nappend;
   const double thr_fin = __longlong_as_double((long long)s_thr[0]);
   const double lost = __longlong_as_double((long long)s_thr[1]);
+  const int xc_flag = XC ? s_cnt[1] : 0;   // an atom (nearly) inside span(x)
   __syncthreads();   // everyone has read the counters / is done with the B buffers
-  if (nappend > a.scap && lost >= thr_fin) {
+  if ((nappend > a.scap && lost >= thr_fin) || xc_flag) {
     // an entry that could still matter was overwritten: hand the voxel to the FP64 kernel
     if (tid == 0) {
       const int slot = atomicAdd(a.fb_count, 1);
       a.fb_list[slot] = vox;
+      if constexpr (XC) a.xl_cnt[blockIdx.x] = -1;
+    }
+    return;
+  }
+  if constexpr (XC) {
+    // short list of the voxel for fit_k2x.hip's exact stage: ring entries that reach the final threshold, then the single
+    // atoms whose one-atom supports could tie with the optimum or whose relaxed score bounds all their pairs ("forced")
+    int* s_evl = (KS >= 8) ? (int*)((char*)smem + 2048) : s_evl4;
+    if (tid == 0) s_cnt[2] = 0;
+    __syncthreads();
+    for (int cix = tid; cix < ncand; cix += WG)
+      if (s_cand[cix].score >= thr_fin) s_evl[atomicAdd(&s_cnt[2], 1)] = cix;
+    __syncthreads();
+    const int neval = s_cnt[2];
+    Cand* dst = a.xl_cand + (size_t)blockIdx.x * a.xl_cap;
+    for (int e = tid; e < min(neval, a.xl_cap); e += WG) {
+      Cand c = s_cand[s_evl[e]];
+      c.score += yx * yx;
+      c.j &= ~MFX_S_BOUND;
+      dst[e] = c;
+    }
+    __syncthreads();
+    const double tcut = thr_fin - 2.0 * mrg;
+    for (int q = tid; q < 2 * NP; q += WG) {
+      const int k = q >= NP, n = q - k * NP;
+      const double npr = (double)s_cs[q];
+      if (n < N && npr > 0.0) {
+        const double zp = (double)s_Zf[q], u = (double)s_uf[q];
+        const double ayv = fma(u, yx, zp * npr);
+        double s1 = (ayv > 0.0 ? ayv * ayv / fma(u, u, npr * npr) : 0.0) - yx * yx;
+        if (zp > -sqrt(mrg)) s1 = fmax(s1, zp > 0.0 ? zp * zp : 0.0);
+        const bool forced = zp > 0.0 && zp * zp >= tcut;
+        if (s1 >= tcut || forced) {
+          const int slot = atomicAdd(&s_cnt[2], 1);
+          const int mark = forced ? -2 : -1;
+          if (slot < a.xl_cap) { Cand c; c.score = s1 + yx * yx; c.i = k ? mark : n; c.j = k ? n : mark; dst[slot] = c; }
+        }
+      }
+    }
+    __syncthreads();
+    const int nall = s_cnt[2];
+    if (tid == 0) {
+      if (nall > a.xl_cap) {   // too many near-ties for the list: the FP64 kernel of the class decides
+        const int slot = atomicAdd(a.fb_count, 1);
+        a.fb_list[slot] = vox;
+        a.xl_cnt[blockIdx.x] = -1;
+      } else {
+        a.xl_cnt[blockIdx.x] = nall;
+        a.xl_mrg[blockIdx.x] = mrg;
+      }
     }
     return;
   }

@@ -789,6 +789,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     }
     __syncthreads();   // s_red is free again
     family_detection();
+    // more families than the exact stage takes (a voxel whose signal is mostly the extra column: every atom's relaxed
+    // score reaches the threshold): not this kernel's exhaustive pass over all tuples - the plain kernel has its own scan
+    // and decides what is really needed
+    if (s_cnt[1] > MFX_XFAM) {
+      if (tid == 0 && !s_cnt[2]) {
+        const int slot = atomicAdd(a.fb_count, 1);
+        a.fb_list[slot] = vox;
+      }
+      return;
+    }
   }
   // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
   const double thr_final = gmax_run - eps_abs;

@@ -439,6 +439,11 @@ size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL) {
          4 * 4 * TL * 64 + (bracket ? 48 * MP : 0) + (KS < 8 ? 4 * MFX_S_CAP : 0);
 }
 
+size_t mfx_k2wx_lds_bytes(int KS, int N, bool bracket, int NB, int TL) {   // + x [MP] and u [2][NP] (FP32)
+  const size_t MP = (size_t)KS * 16, NP = ((size_t)N + 31) / 32 * 32;
+  return mfx_k2w_lds_bytes(KS, N, bracket, NB, TL) + 4 * MP + 8 * NP;
+}
+
 // Which kernel serves a two-fascicle class:
 //   M <= 256: the two-waves-per-SIMD screening kernel (fit_k2s.hip), or - MFX_K2_WIDE=1 / mfx_debug_set_k2_wide(1) - the
 //             wide one (fit_k2w.hip, KS = 13 / 16);

@@ -114,6 +114,9 @@ size_t mfx_k2sx_lds_bytes(int KS, int N, bool bracket, int NB);
 int mfx_launch_k2sx_ks8(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2sx_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 size_t mfx_k2w_lds_bytes(int KS, int N, bool bracket, int NB, int TL);
+size_t mfx_k2wx_lds_bytes(int KS, int N, bool bracket, int NB, int TL);
+int mfx_launch_k2wx_ks24(const FitK2Args& a, int nvox, hipStream_t st, bool br);
+int mfx_launch_k2wx_ks35(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2w_ks13(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2w_ks16(const FitK2Args& a, int nvox, hipStream_t st, bool br);
 int mfx_launch_k2w_ks24(const FitK2Args& a, int nvox, hipStream_t st, bool br);

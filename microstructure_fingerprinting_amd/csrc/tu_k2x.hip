@@ -57,10 +57,9 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
 //      list; a listed pair that beats its own bound by more than the margin hands the voxel back as well;
 //   3. after the last chunk the plain kernel redoes the handed-back voxels from the device-side list (no host read).
 // MFX_K2X_SCREEN=0 keeps every voxel on the plain kernel.
-template <int KSTEPS, bool BRACKET>
+template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
 static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   MfxThread& T = mfx_thread();
-  constexpr int NW = 8, NBUF = 2;
   const int ntup = 1;
   size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, a.P.M, a.X.NX);
   a.xx_in_lds = 1;
@@ -101,7 +100,7 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
     const int n = std::min(big, nvox - base);
     s.vox_base = base;
     const int M = a.P.M;
-    if (int rc = (M < 128 ? mfx_launch_k2sx_ks8 : mfx_launch_k2sx_ks13)(s, n, st, BRACKET)) return rc;
+    if (int rc = (M < 128 ? mfx_launch_k2sx_ks8 : (M <= 200 ? mfx_launch_k2sx_ks13 : (M < 384 ? mfx_launch_k2wx_ks24 : mfx_launch_k2wx_ks35)))(s, n, st, BRACKET)) return rc;
     a.vox_base = base;
     hipLaunchKernelGGL(kern_list, dim3(n), dim3(NW * 64), lds, st, a);
   }
@@ -131,6 +130,12 @@ int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
         mfx_k2sx_lds_bytes(ksx, a.T.N, br, 2) <= 160 * 1024) {
       if (M == 64) return br ? launch_k2sx_pipeline<16, true>(a, nvox, st) : launch_k2sx_pipeline<16, false>(a, nvox, st);
       return br ? launch_k2sx_pipeline<50, true>(a, nvox, st) : launch_k2sx_pipeline<50, false>(a, nvox, st);
+    }
+    // longer protocols: the wide screening kernel in its [N, N, 1] form (24 / 35 k-steps; one padded row must stay free)
+    if (T.k2x_screen && T.k2x_maxc == MFX_XMAXC && a.X.has_csf && a.X.E == 0 && a.X.NX == 1 && M > 200 && M < 560 &&
+        mfx_k2wx_lds_bytes(M < 384 ? 24 : 35, a.T.N, br, 1, 1) <= 160 * 1024) {
+      if (M <= 400) return br ? launch_k2sx_pipeline<100, true, 4, 1>(a, nvox, st) : launch_k2sx_pipeline<100, false, 4, 1>(a, nvox, st);
+      return br ? launch_k2sx_pipeline<140, true, 4, 1>(a, nvox, st) : launch_k2sx_pipeline<140, false, 4, 1>(a, nvox, st);
     }
   }
   if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);

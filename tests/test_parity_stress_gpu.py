@@ -722,3 +722,53 @@ def test_mixed_classes_full_size_vs_oracle():
     rows = (V + np.arange(V)).astype(np.int64)
     got2 = engine.fit_batch(plan, vol, K, csf, zero, peaks, 2, True, False, sig_csf, None, 0, rows=rows)
     assert np.array_equal(got, got2)
+
+
+@pytest.mark.parametrize("dirs", [[100, 100, 100], [137, 137, 137, 139]])
+def test_k2_csf_pipeline_long_protocols_vs_plain_kernel_and_oracle(dirs):
+    """[782, 782, 1] with 302 / 552 measurements (HCP-MGH length): the wide screening kernel in its XC form + list-mode exact
+    stage against the plain FP64 kernel of the class (bit-identical, incl. pure-CSF and one-fascicle voxels) and the oracle."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(31)
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000, 5000][:len(dirs)], dirs)
+    N, V = 782, 1536
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    M = plan.M
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3.0e-9)
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(3), V)
+    kind = np.arange(V) % 8
+    nu[kind == 1, 2] = 0
+    nu[kind == 2, 1] = 0
+    nu[kind == 3] = [0, 0, 1]
+    p2[kind == 4] = _second_peak(rng, p1[kind == 4], 3.0)
+    nu /= nu.sum(1, keepdims=True)
+    Y = 500.0 * (nu[:, :1] * _rotate_cols(plan, p1, atoms[:, 0]) + nu[:, 1:2] * _rotate_cols(plan, p2, atoms[:, 1]) + nu[:, 2:3] * sig_csf)
+    noise = rng.normal(0, 500.0 / 30.0, (V, M))
+    noise[kind == 5] = 0.0
+    Y = Y + noise
+    peaks = np.concatenate([p1, p2], axis=1)
+    one, zero = np.ones(V, bool), np.zeros(V, bool)
+    lib = L.lib()
+    args = (plan, Y, np.full(V, 2), one, zero, peaks, 2, True, False, sig_csf, None, 0)
+    got = engine.fit_batch(*args)
+    cn = [lib.mfx_debug_last_counter(q) for q in range(6)]
+    lib.mfx_debug_set_k2x_screen(0)
+    try:
+        plain = engine.fit_batch(*args)
+    finally:
+        lib.mfx_debug_set_k2x_screen(1)
+    assert np.array_equal(got, plain), "rows differ: %s" % np.flatnonzero(np.any(got != plain, axis=1))[:10]
+    assert cn[5] == 0 and cn[4] <= 0.4 * V
+    ns = 48
+    ref = orc.fit_batch(_tables(ms), sch, Y[:ns], np.full(ns, 2), one[:ns], zero[:ns], peaks[:ns], 2, True, False, sig_csf, None, 0,
+                        nthreads=NTHREADS)
+    _assert_rows(got[:ns], ref, 2, "[782,782,1] screening pipeline, %d rows" % M, rtol=1e-9)
