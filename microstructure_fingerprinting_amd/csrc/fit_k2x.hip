@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
 #pragma unroll
     for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bs2[r] = 0.0; bj[r] = -1; }
     // filter constants of this wave's 16 rows for the threshold thr_rows (refreshed when the threshold has risen)
-    double thr_rows = -1.0;
+    double thr_rows = -INFINITY;   // (T = threshold - 1e-9 |y|^2 is below -1 for a large weak signal: no finite sentinel)
     auto row_consts = [&](double T) {
       thr_rows = T;
       for (int q = lane; q < 16 * (ntup + 1); q += 64) {

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,44 @@ int mfx_fail(int code, const char* fmt, ...) {
   return code;
 }
 #define fail mfx_fail
+
+// ---- scratch pool (mfx_host.h): one per device, created at first use, never trimmed
+namespace {
+constexpr int MFX_MAXDEV = 64;
+std::mutex g_pool_mutex;
+hipMemPool_t g_pool[MFX_MAXDEV] = {};
+int poison_byte() {
+  static const int b = [] { const char* e = std::getenv("MFX_POISON"); return e ? (std::atoi(e) & 0xff) : -1; }();
+  return b;
+}
+}  // namespace
+hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= MFX_MAXDEV) return hipErrorInvalidDevice;
+  hipMemPool_t pool;
+  {
+    std::lock_guard<std::mutex> g(g_pool_mutex);
+    if (!g_pool[dev]) {
+      hipMemPoolProps props{};
+      props.allocType = hipMemAllocationTypePinned;
+      props.handleTypes = hipMemHandleTypeNone;
+      props.location.type = hipMemLocationTypeDevice;
+      props.location.id = dev;
+      hipMemPool_t np = nullptr;
+      if ((e = hipMemPoolCreate(&np, &props)) != hipSuccess) return e;
+      uint64_t keep = UINT64_MAX;
+      if ((e = hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) { (void)hipMemPoolDestroy(np); return e; }
+      g_pool[dev] = np;
+    }
+    pool = g_pool[dev];
+  }
+  if (!bytes) bytes = 8;
+  if ((e = hipMallocFromPoolAsync(p, bytes, pool, s)) != hipSuccess) return e;
+  if (poison_byte() >= 0) e = hipMemsetAsync(*p, poison_byte(), bytes, s);
+  return e;
+}
 
 int mfx_prof_begin(hipStream_t st) {
   MfxThread& T = mfx_thread();
@@ -499,8 +538,8 @@ struct ExtrasHost {
     if (NX > MFX_NXMAX) return fail(MFX_ERR_UNSUPPORTED, "at most %d CSF+EAR columns are supported (got %d)", MFX_NXMAX, NX);
     if (has_csf && !d_sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
     if (E && !d_sig_ear) return fail(MFX_ERR_ARG, "sig_ear missing");
-    HIPCHK(hipMallocAsync(&dx, sizeof(double) * (size_t)M * NX, st));
-    HIPCHK(hipMallocAsync(&dG, sizeof(double) * (size_t)NX * NX, st));
+    HIPCHK(mfx_scratch_alloc(&dx, sizeof(double) * (size_t)M * NX, st));
+    HIPCHK(mfx_scratch_alloc(&dG, sizeof(double) * (size_t)NX * NX, st));
     hipLaunchKernelGGL(mfx_extras_kernel, dim3(1), dim3(256), 0, st, d_sig_csf, d_sig_ear, M, has_csf, E, (double*)dx, (double*)dG);
     HIPCHK(hipGetLastError());
     d.x = (const double*)dx;

@@ -77,6 +77,14 @@ struct DevMem {
   void* release() { void* q = p; p = nullptr; return q; }
   template <class T> T* as() const { return (T*)p; }
 };
+// Stream-ordered scratch memory comes from ONE library-owned memory pool per device whose release threshold is
+// unlimited: what a call allocates stays mapped for the next one.  (HIP's default pool hands its memory back to the
+// driver at every stream synchronisation and maps it again at the next call; on the MI355X box of round 2 kernels then
+// read stale data through the re-mapped addresses on some XCDs - repeated mfx_fit_batch calls on identical inputs
+// returned different rows for blocks of voxels)  mfx_scratch_alloc fails loudly if the pool cannot
+// be created.  MFX_POISON=<byte>: every scratch allocation is filled with that byte before use (developer check for
+// reads of uninitialised scratch memory).
+hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s);
 // stream-ordered allocation released (in stream order) on every exit path
 struct StreamMem {
   void* p = nullptr;
@@ -85,7 +93,7 @@ struct StreamMem {
   StreamMem(const StreamMem&) = delete;
   StreamMem& operator=(const StreamMem&) = delete;
   ~StreamMem() { if (p) (void)hipFreeAsync(p, s); }
-  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, s); }
+  hipError_t alloc(size_t bytes) { return mfx_scratch_alloc(&p, bytes, s); }
   template <class T> T* as() const { return (T*)p; }
 };
 

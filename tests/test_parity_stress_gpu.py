@@ -684,6 +684,37 @@ def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     _assert_rows(got[:ns], ref, 2, "[782,782,1] screening pipeline", rtol=1e-9)
 
 
+def test_repeated_small_host_calls_are_reproducible():
+    """The same 64 two-fascicle + CSF voxels through the host entry point thirty times, the screening pipeline switched on
+    and off in between: every call must return the oracle's rows.  (Regression: with scratch memory from HIP's default
+    stream-ordered pool - unmapped at every synchronisation, mapped again by the next call - some of these calls came back
+    with blocks of about 8 voxels fitted on stale data; the library now owns a pool that keeps its memory, mfx_host.h.)"""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from oracle import oracle as orc
+    N, V = 782, 64
+    sch, ms, sig_csf, _, _ = _c4_model(N, 4)
+    plan = ms.plan_for(sch)
+    M = plan.M
+    rng = np.random.default_rng(5)
+    p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
+    atoms = rng.integers(0, N, (V, 2))
+    Y = 500.0 * (0.4 * _rotate_cols(plan, p1, atoms[:, 0]) + 0.4 * _rotate_cols(plan, p2, atoms[:, 1]) + 0.2 * sig_csf) + rng.normal(0, 16, (V, M))
+    peaks = np.concatenate([p1, p2], axis=1)
+    one, zero = np.ones(V, bool), np.zeros(V, bool)
+    args = (plan, Y, np.full(V, 2), one, zero, peaks, 2, True, False, sig_csf, None, 0)
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), one, zero, peaks, 2, True, False, sig_csf, None, 0, nthreads=NTHREADS)
+    lib = L.lib()
+    try:
+        for rep in range(3):
+            for scr in (1, 0):
+                lib.mfx_debug_set_k2x_screen(scr)
+                for k in range(5):
+                    _assert_rows(engine.fit_batch(*args), ref, 2, "repeat %d, screening %d, call %d" % (rep, scr, k + 1), rtol=1e-9)
+    finally:
+        lib.mfx_debug_set_k2x_screen(1)
+
+
 def test_mixed_classes_full_size_vs_oracle():
     """A mixed ROI at BASELINE config 2's size (782 atoms x 200 measurements) through the host entry point: voxels with 0, 1
     or 2 fascicles, with and without the CSF flag, interleaved - every class goes through its own kernel from per-chunk
