@@ -74,7 +74,7 @@ struct FitK2XArgs {
 
 #define MFX_XFAM 64   // family items (see below) per voxel before the exhaustive pass takes over
 struct FamX {
-  int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (0, 0, t): no fascicle atom active   4: (i, j = lc mod 16, all t)
+  int type;   // 1: (i, all j, t)   2: (all i, j, t)   3: (0, 0, t): no fascicle atom active
   int a, t;
 };
 
@@ -93,14 +93,19 @@ __device__ __forceinline__ ProjC mfx_ldc(const ProjC* p) {
   c.qn = __uint_as_float(r[3]);
   return c;
 }
+#define MFX_XQ 64   // entries of a wave's queue of passing tuples: one scoring pass with every lane busy
+struct QItem {   // a tuple that passed the filter: the owner lane writes (v = a1.a2, code), the scoring lane answers v = score
+  double v;
+  int code, pad;   // row in the wave's tile | column in the chunk << 4 | tuple << 8
+};
 struct ProjB {   // threshold-independent part of the filter constants of one (atom, extra tuple), computed once per voxel
   double u;      // as ProjC::u (entry ntup of an atom: its d . f / |f|)
   float np, zp;  // |d'| (0: d' vanishes, the atom passes with every partner) and d'.y' / |d'|
 };
 
-struct CandX {
+struct CandX {   // short-list entry: a pair of atoms and its ranking score
   double score;
-  int i, j, e, pad;
+  int i, j;
 };
 
 // NW waves per workgroup and NBUF LDS chunk buffers: (8, 2) for M <= 200, (4, 1) for long protocols
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
   double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
   double* s_Qx = s_red + 32;                      // [XS]            best support made of extra columns only, per extra tuple
-  CandX* s_cand = (CandX*)(s_Qx + MFX_XS);        // [XMAXC]
+  CandX* s_cand = (CandX*)(s_Qx + MFX_XS);        // [NW][XMAXC / NW] every wave's own short list
   FamX* s_fam = (FamX*)(s_cand + MFX_XMAXC);      // [XFAM]
   double* s_tc = (double*)(s_fam + MFX_XFAM);     // [XS][4] per extra tuple: l_t, 1/r_t, y.x_t', q0_t   + [2]: 1/|f|, y.f/|f|
   double* s_rowf = s_tc + 4 * MFX_XS + 2;         // [NW][16] d1 . f / |f| of each wave's rows
@@ -147,10 +152,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   unsigned long long* s_thr = (unsigned long long*)(s_colf + 2 * 16);   // [2] best NNLS score so far (bits of a non-negative double)
   ProjC* s_rowc = (ProjC*)(s_thr + 2);            // [NW][16][ntup]
   ProjC* s_colc = s_rowc + NW * 16 * ntup;        // [2][16][ntup]
-  double* s_xx = (double*)(s_colc + 2 * 16 * ntup);   // [M][NX] the extra columns (read by every row of every sum: LDS, not global loads)
+  QItem* s_q = (QItem*)(s_colc + 2 * 16 * ntup);  // [NW][MFX_XQ] per wave: tuples that passed the filter, waiting for their score
+  double* s_xx = (double*)(s_q + NW * MFX_XQ);    // [M][NX] the extra columns (read by every row of every sum: LDS, not global loads)
   int* s_r0 = (int*)(s_xx + (a.xx_in_lds ? (size_t)M * NX : 0));      // [2][MP]
   int* s_r1 = s_r0 + 2 * MP;
-  int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);
+  int* s_cnt = s_r1 + (BRACKET ? 2 * MP : 0);     // [4]
+  int* s_qn = s_cnt + 4;                          // [NW][2] per wave: a 64-bit scratch word of the queue logic (8-byte aligned)
 
   MFX_STAMP(0);
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     const int p = q / MFX_XS, r = q - p * MFX_XS;
     s_Gxx[q] = (p < NX && r < NX) ? a.X.Gxx[p * NX + r] : 0.0;
   }
-  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; }
   if (tid < 2) mfx_check_dir(a.P, pk + 3 * tid, vox);
   __syncthreads();
   if (tid < MFX_XS) {
@@ -410,6 +417,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   const double eps_abs = eps_abs_of * y_sq;
   MFX_STAMP(2);
 
+  // Every wave keeps its own short list: each scored tuple within the tie tolerance of the best score known at that
+  // moment is appended (so everything within the tolerance of the FINAL best is in some list); a full list is compacted
+  // against the current threshold, and if that does not make room the voxel takes the exhaustive pass.
+  constexpr int WCAP = MFX_XMAXC / NW;
+  static_assert(WCAP <= 64, "a wave compacts its list in one pass");
+  const int wcap = a.maxc >= MFX_XMAXC ? WCAP : max(1, a.maxc / NW);   // (tests lower maxc to force the exhaustive pass)
+  CandX* wl = s_cand + wave * WCAP;
+  int wn = 0, wovf = 0;   // wave-uniform: entries in the wave's list, overflow seen
+
   for (int round = 0; round < nrounds; ++round) {
     const int rt = round * NW + wave;
     const bool rt_valid = rt < ntiles;
@@ -420,10 +436,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     if (rt_valid) {
       for (int q = lane; q < 16 * MFX_XS; q += 64) s_a1x[wave * 16 * MFX_XS + q] = wsA[((size_t)rt * 16) * MFX_XS + q];
     }
-    double bs[4], bs2[4];   // best and runner-up score of the (lane,row) slot
-    int bj[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { bs[r] = 0.0; bs2[r] = 0.0; bj[r] = -1; }
     // filter constants of this wave's 16 rows for the threshold thr_rows (refreshed when the threshold has risen)
     double thr_rows = -INFINITY;   // (T = threshold - 1e-9 |y|^2 is below -1 for a large weak signal: no finite sentinel)
     auto row_consts = [&](double T) {
@@ -489,57 +501,107 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       MFX_XSTAMP(3);
       if (rt_valid) {
         const int j = ch * 16 + lc;
+        // ---- filter: which tuples of the lane's four pairs can reach the threshold at all (see the top of the file).
+        // fm[r]: shift register of the tests' sign bits (set = the tuple fails), tuple t ends up in bit ntup - 1 - t
+        unsigned fm[4] = {~0u, ~0u, ~0u, ~0u};
         if (j < N) {
-          // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports whose
-          // unconstrained solution is non-negative.  Only the supports with BOTH fascicle atoms are ranked here (the
-          // others come from the per-atom scores, see the top of the file); per pair the {1,2}(+fixed) block is
-          // eliminated once (LDL^T), per extra column only the last row is added.
-          const double a22 = s_A22[j], y2 = s_Y2[j];
-          const double* a2x = s_a2x + (buf * 16 + lc) * MFX_XS;
-          // ---- filter: which tuples of the lane's four pairs can reach the threshold at all (see the top of the file)
-          unsigned sgn[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};   // sign bit cleared: some tuple of the pair passes
-          double accf[4];
           const ProjC* cc = s_colc + (buf * 16 + lc) * ntup;
           const ProjC* rc = s_rowc + (wave * 16 + lg) * ntup;
-          {
-            const double uf2 = s_colf[buf * 16 + lc];
+          const double uf2 = s_colf[buf * 16 + lc];
+          double accf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accf[r] = HASF ? fma(-s_rowf[wave * 16 + lg + 4 * r], uf2, acc[r]) : acc[r];
-            const ProjC* r0p = rc, *r1p = rc + 4 * ntup, *r2p = rc + 8 * ntup, *r3p = rc + 12 * ntup;
+          for (int r = 0; r < 4; ++r) accf[r] = HASF ? fma(-s_rowf[wave * 16 + lg + 4 * r], uf2, acc[r]) : acc[r];
+          const ProjC* r0p = rc, *r1p = rc + 4 * ntup, *r2p = rc + 8 * ntup, *r3p = rc + 12 * ntup;
 #pragma unroll 2
-            for (int t = 0; t < ntup; ++t) {
-              const ProjC c2 = mfx_ldc(cc + t);
-              const ProjC c10 = mfx_ldc(r0p + t), c11 = mfx_ldc(r1p + t), c12 = mfx_ldc(r2p + t), c13 = mfx_ldc(r3p + t);
-              const float b0 = fmaf(-c10.qn, c2.qn, fmaf(c10.pn, c2.pn, -(float)fma(-c10.u, c2.u, accf[0])));
-              const float b1 = fmaf(-c11.qn, c2.qn, fmaf(c11.pn, c2.pn, -(float)fma(-c11.u, c2.u, accf[1])));
-              const float b2 = fmaf(-c12.qn, c2.qn, fmaf(c12.pn, c2.pn, -(float)fma(-c12.u, c2.u, accf[2])));
-              const float b3 = fmaf(-c13.qn, c2.qn, fmaf(c13.pn, c2.pn, -(float)fma(-c13.u, c2.u, accf[3])));
-              // "some tuple passes" = some b has its sign bit clear: AND of the bit patterns, one instruction per test
-              sgn[0] &= __float_as_uint(b0); sgn[1] &= __float_as_uint(b1);
-              sgn[2] &= __float_as_uint(b2); sgn[3] &= __float_as_uint(b3);
-            }
+          for (int t = 0; t < ntup; ++t) {
+            const ProjC c2 = mfx_ldc(cc + t);
+            const ProjC c10 = mfx_ldc(r0p + t), c11 = mfx_ldc(r1p + t), c12 = mfx_ldc(r2p + t), c13 = mfx_ldc(r3p + t);
+            const float b0 = fmaf(-c10.qn, c2.qn, fmaf(c10.pn, c2.pn, -(float)fma(-c10.u, c2.u, accf[0])));
+            const float b1 = fmaf(-c11.qn, c2.qn, fmaf(c11.pn, c2.pn, -(float)fma(-c11.u, c2.u, accf[1])));
+            const float b2 = fmaf(-c12.qn, c2.qn, fmaf(c12.pn, c2.pn, -(float)fma(-c12.u, c2.u, accf[2])));
+            const float b3 = fmaf(-c13.qn, c2.qn, fmaf(c13.pn, c2.pn, -(float)fma(-c13.u, c2.u, accf[3])));
+            // one instruction per test: the sign bit (clear = the tuple passes) is shifted in
+            fm[0] = __builtin_amdgcn_alignbit(fm[0], __float_as_uint(b0), 31);
+            fm[1] = __builtin_amdgcn_alignbit(fm[1], __float_as_uint(b1), 31);
+            fm[2] = __builtin_amdgcn_alignbit(fm[2], __float_as_uint(b2), 31);
+            fm[3] = __builtin_amdgcn_alignbit(fm[3], __float_as_uint(b3), 31);
           }
-          unsigned pass[4];
+        }
+        // ---- the passing tuples of the wave's 256 pairs are COMPACTED before they are scored: a few percent of the
+        // tuples pass, scattered over the lanes - scored in place, the ~100-instruction FP64 scoring ran for almost every
+        // (row group, tuple) with a handful of lanes active (45 % of a config-4 voxel's time).  The wave goes through the
+        // (row group, tuple) combinations some lane passes: the passing lanes append (a1.a2, who they are) to the wave's
+        // 64-entry LDS queue; a queue that cannot take the next combination is scored first, all lanes busy.
+        MFX_XSTAMP(6);
+        const unsigned allt = (1u << ntup) - 1u;
+        unsigned long long pmask = 0ull;   // bit 16 r + (ntup - 1 - t): tuple t of the lane's pair r passes
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pass[r] = (sgn[r] >> 31) ^ 1u;
+        for (int r = 0; r < 4; ++r)
+          pmask |= (unsigned long long)((j < N && rt * 16 + lg + 4 * r < N) ? (~fm[r] & allt) : 0u) << (16 * r);
 #ifdef MFX_STAMPS
-          if (a.stamps) {   // diagnostics: tuples that pass the filter / (wave, row group) scoring passes executed
-            const int np_ = (int)(pass[0] + pass[1] + pass[2] + pass[3]);   // pairs with a passing tuple
-            if (np_) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)np_);
-            for (int r = 0; r < 4; ++r) {
-              const unsigned long long bal = __ballot(pass[r] != 0);
-              if (bal && lane == __ffsll((long long)bal) - 1) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 11], 1ull);
-            }
-          }
+        if (a.stamps && pmask) atomicAdd(&a.stamps[(size_t)blockIdx.x * 16 + 10], (unsigned long long)__builtin_popcountll(pmask));   // diagnostics: tuples that pass the filter
 #endif
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int il = lg + 4 * r;
-            const int i = rt * 16 + il;
-            if (i < N && pass[r]) {
-              const double a11 = s_A11[i], y1 = s_Y1[i], a12 = acc[r];
+        if (__builtin_amdgcn_ballot_w64(pmask != 0ull)) {   // wave-uniform
+          // the combinations present in the wave: OR of the lanes' masks (a wave's LDS operations execute in order and the
+          // word is the wave's own: no barrier)
+          unsigned long long* wor_p = (unsigned long long*)(s_qn + 2 * wave);
+          if (lane == 0) *wor_p = 0ull;
+          if (pmask) atomicOr(wor_p, pmask);
+          unsigned long long wor = *wor_p;
+          wor = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wor >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)wor);
+          QItem* q = s_q + wave * MFX_XQ;
+          int qn = 0;   // wave-uniform fill of the queue
+#ifdef MFX_STAMPS_W
+          unsigned long long dbg_total = 0;
+#endif
+          for (bool more = true; more;) {
+            // next combination (or none left: the last pass only scores what is queued)
+            const bool have = wor != 0ull;
+            const int kb = have ? __ffsll((long long)wor) - 1 : 0;
+            wor &= wor - 1ull;
+            const bool p = have && ((pmask >> kb) & 1ull);
+            const unsigned long long pb = __builtin_amdgcn_ballot_w64(p);
+            const int n = __builtin_popcountll(pb);
+            more = have;
+            if (qn + n <= MFX_XQ && have) {   // room: append and go on
+              if (p) {
+                const int r = kb >> 4, t = ntup - 1 - (kb & 15);
+                const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pb, 0u));
+                q[slot].v = r == 0 ? acc[0] : (r == 1 ? acc[1] : (r == 2 ? acc[2] : acc[3]));
+                q[slot].code = (lg + 4 * r) | (lc << 4) | (t << 8);
+              }
+              qn += n;
+              continue;
+            }
+            if (have) wor |= 1ull << kb;   // the combination waits for the queue to drain
+            more = have;
+            const int nq = qn;
+            qn = 0;
+            if (nq == 0) continue;
+#ifdef MFX_STAMPS_W
+            dbg_total += nq;
+#endif
+            __builtin_amdgcn_wave_barrier();
+            double sc = -1.0;
+            int ci = 0, cj = 0;
+            if (lane < nq) {
+              const int code = q[lane].code;
+              const double a12 = q[lane].v;
+              const int il = code & 15, cl = (code >> 4) & 15, t = code >> 8;
+              const int i = rt * 16 + il, jj = ch * 16 + cl;
+              ci = i; cj = jj;
               const double* a1x = s_a1x + (wave * 16 + il) * MFX_XS;
-              // LDL^T of the {1,2} block
+              const double* a2x = s_a2x + (buf * 16 + cl) * MFX_XS;
+              const int cx = x0 + t;
+              // every operand is read up front, in one batch of LDS reads (reads scattered between the dependent FP64
+              // steps cost a wave that scores alone an LDS round trip each)
+              const double a11 = s_A11[i], y1 = s_Y1[i], a22 = s_A22[jj], y2 = s_Y2[jj];
+              const double a1f = a1x[0], a2f = a2x[0], aff = s_Gxx[0], yf = s_Yx[0];
+              const double a1e = a1x[cx], a2e = a2x[cx], aee = s_Gxx[cx * MFX_XS + cx], ye = s_Yx[cx], afe = s_Gxx[cx];
+              // Ranking by feasible supports: the NNLS optimum of a tuple is the best score among the supports whose
+              // unconstrained solution is non-negative.  Only the supports with BOTH fascicle atoms are ranked here (the
+              // others come from the per-atom scores, see the top of the file): LDL^T of the {1,2}(+fixed) block, the
+              // tuple's extra column as the last row.
               const double ip1 = mfx_rcp(a11);
               const double l21 = a12 * ip1;
               const double p2 = fma(-l21, a12, a22);
@@ -549,12 +611,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
               const double v1 = y1 * ip1, v2 = u2 * ip2;
               const double S2u = fma(u2, v2, y1 * v1);
               const double w1p = fma(-l21, v2, v1);
-              double s = (ok2 && w1p >= 0.0 && v2 >= 0.0) ? S2u : 0.0;   // {1,2}
+              sc = (ok2 && w1p >= 0.0 && v2 >= 0.0) ? S2u : 0.0;   // {1,2}
               // fixed (CSF) column: extend the elimination by one row
               double l31 = 0.0, b23 = 0.0, l32 = 0.0, ip3 = 0.0, u3 = 0.0, v3 = 0.0, S3u = 0.0;
               bool ok3 = false;
               if (HASF) {
-                const double a1f = a1x[0], a2f = a2x[0], aff = s_Gxx[0], yf = s_Yx[0];
                 l31 = a1f * ip1;
                 b23 = fma(-l21, a1f, a2f);
                 l32 = b23 * ip2;
@@ -566,51 +627,68 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
                 S3u = fma(u3, v3, S2u);
                 const double w2f = fma(-l32, v3, v2);
                 const double w1f = fma(-l31, v3, fma(-l21, w2f, v1));
-                s = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(s, S3u) : s;  // {1,2,f}
+                sc = (ok3 && w1f >= 0.0 && w2f >= 0.0 && v3 >= 0.0) ? fmax(sc, S3u) : sc;  // {1,2,f}
               }
-              for (int t = 0; t < ntup; ++t) {
-                {   // the filter again, for this tuple alone (the pass above only kept "some tuple passes")
-                  const ProjC c2 = mfx_ldc(cc + t), c1 = mfx_ldc(rc + 4 * r * ntup + t);
-                  if (!(fmaf(-c1.qn, c2.qn, fmaf(c1.pn, c2.pn, -(float)fma(-c1.u, c2.u, accf[r]))) >= 0.0f)) continue;
-                }
-                const int cx = x0 + t;
-                const double a1e = a1x[cx], a2e = a2x[cx], aee = s_Gxx[cx * MFX_XS + cx], ye = s_Yx[cx];
-                // support {1,2,x}: last row of the LDL^T on top of the {1,2} block
-                const double m1 = a1e * ip1;
-                const double t2 = fma(-m1, a12, a2e);
-                const double m2 = t2 * ip2;
-                {
-                  const double p3x = fma(-m2, t2, fma(-m1, a1e, aee));
-                  const double u3x = fma(-m2, u2, fma(-m1, y1, ye));
-                  const bool okx = ok2 && (p3x > 1e-8 * aee);
-                  const double w3 = u3x * mfx_rcp(okx ? p3x : 1.0);
-                  const double w2 = fma(-m2, w3, v2);
-                  const double w1 = fma(-m1, w3, fma(-l21, w2, v1));
-                  s = (okx && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0) ? fmax(s, fma(u3x, w3, S2u)) : s;
-                }
-                if (HASF) {  // support {1,2,f,x}: last row on top of the {1,2,f} block
-                  const double afe = s_Gxx[cx];
-                  const double t3 = fma(-m2, b23, fma(-m1, a1x[0], afe));
-                  const double m3 = t3 * ip3;
-                  const double p4 = fma(-m3, t3, fma(-m2, t2, fma(-m1, a1e, aee)));
-                  const double u4 = fma(-m3, u3, fma(-m2, u2, fma(-m1, y1, ye)));
-                  const bool ok4 = ok3 && (p4 > 1e-8 * aee);
-                  const double w4 = u4 * mfx_rcp(ok4 ? p4 : 1.0);
-                  const double w3 = fma(-m3, w4, v3);
-                  const double w2 = fma(-m2, w4, fma(-l32, w3, v2));
-                  const double w1 = fma(-m1, w4, fma(-l31, w3, fma(-l21, w2, v1)));
-                  s = (ok4 && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0 && w4 >= 0.0) ? fmax(s, fma(u4, w4, S3u)) : s;
-                }
+              // support {1,2,x}: last row of the LDL^T on top of the {1,2} block
+              const double m1 = a1e * ip1;
+              const double t2 = fma(-m1, a12, a2e);
+              const double m2 = t2 * ip2;
+              {
+                const double p3x = fma(-m2, t2, fma(-m1, a1e, aee));
+                const double u3x = fma(-m2, u2, fma(-m1, y1, ye));
+                const bool okx = ok2 && (p3x > 1e-8 * aee);
+                const double w3 = u3x * mfx_rcp(okx ? p3x : 1.0);
+                const double w2 = fma(-m2, w3, v2);
+                const double w1 = fma(-m1, w3, fma(-l21, w2, v1));
+                sc = (okx && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0) ? fmax(sc, fma(u3x, w3, S2u)) : sc;
+              }
+              if (HASF) {  // support {1,2,f,x}: last row on top of the {1,2,f} block
+                const double t3 = fma(-m2, b23, fma(-m1, a1f, afe));
+                const double m3 = t3 * ip3;
+                const double p4 = fma(-m3, t3, fma(-m2, t2, fma(-m1, a1e, aee)));
+                const double u4 = fma(-m3, u3, fma(-m2, u2, fma(-m1, y1, ye)));
+                const bool ok4 = ok3 && (p4 > 1e-8 * aee);
+                const double w4 = u4 * mfx_rcp(ok4 ? p4 : 1.0);
+                const double w3 = fma(-m3, w4, v3);
+                const double w2 = fma(-m2, w4, fma(-l32, w3, v2));
+                const double w1 = fma(-m1, w4, fma(-l31, w3, fma(-l21, w2, v1)));
+                sc = (ok4 && w1 >= 0.0 && w2 >= 0.0 && w3 >= 0.0 && w4 >= 0.0) ? fmax(sc, fma(u4, w4, S3u)) : sc;
               }
               // a better score raises the workgroup's threshold (the filter constants follow at their next refresh)
-              if (s > __longlong_as_double((long long)s_thr[0])) atomicMax(&s_thr[0], (unsigned long long)__double_as_longlong(s));
-              // slot update: columns come in increasing j, strict '>' keeps the first of equal scores
-              const bool better = s > bs[r];
-              bs2[r] = better ? bs[r] : fmax(bs2[r], s);
-              bj[r] = better ? j : bj[r];
-              bs[r] = better ? s : bs[r];
+              if (sc > __longlong_as_double((long long)s_thr[0])) atomicMax(&s_thr[0], (unsigned long long)__double_as_longlong(sc));
             }
+            // ---- short list: whatever is within the tie tolerance of the best score so far (wave-uniform code)
+            const double Tn = __longlong_as_double((long long)s_thr[0]) - eps_abs;
+            const bool want = sc > 0.0 && sc >= Tn;
+            const unsigned long long wb = __builtin_amdgcn_ballot_w64(want);
+            if (wb) {
+              const int need = __builtin_popcountll(wb);
+              if (wn + need > wcap) {   // make room: drop what the risen threshold has left behind
+                CandX ent;
+                ent.score = 0.0; ent.i = 0; ent.j = 0;
+                bool keep = false;
+                if (lane < wn) { ent = wl[lane]; keep = ent.score >= Tn; }
+                const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
+                // (every lane has read its entry before any lane writes: one instruction stream)
+                if (keep) wl[__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u))] = ent;
+                wn = __builtin_popcountll(kb);
+              }
+              if (wn + need > wcap) {
+                wovf = 1;
+              } else {
+                if (want) {
+                  CandX ent;
+                  ent.score = sc; ent.i = ci; ent.j = cj;
+                  wl[wn + __builtin_amdgcn_mbcnt_hi((unsigned)(wb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wb, 0u))] = ent;
+                }
+                wn += need;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();   // the next combinations overwrite the queue
           }
+#ifdef MFX_STAMPS_W
+          if (a.stamps && round == 1 && ch == 10 && (tid == 0 || tid == WG - 64)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + 7] = dbg_total;
+#endif
         }
       }
       MFX_XSTAMP(4);
@@ -618,35 +696,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       MFX_XSTAMP(5);
     }
     if (round == 0) MFX_STAMP(5);
-    double lmax = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lmax = fmax(lmax, bs[r]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o));
-    if (lane == 0) s_red[wave] = lmax;
-    __syncthreads();
-    double rmax = s_red[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) rmax = fmax(rmax, s_red[w]);
-    gmax_run = fmax(gmax_run, rmax);
-    const double thr = gmax_run - eps_abs;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (bj[r] >= 0 && bs[r] >= thr) {
-        const int slot = atomicAdd(&s_cnt[0], 1);
-        if (slot < MFX_XMAXC) {
-          s_cand[slot].score = bs[r];
-          s_cand[slot].i = rt * 16 + lg + 4 * r;
-          s_cand[slot].j = bj[r];
-          s_cand[slot].e = 0;
-        }
-        if (bs2[r] >= thr) {   // the slot's runner-up could be the reference's pick too: its whole slot row goes exact
-          const int f = atomicAdd(&s_cnt[1], 1);
-          if (f < MFX_XFAM) { s_fam[f].type = 4; s_fam[f].a = rt * 16 + lg + 4 * r; s_fam[f].t = lc; }
-        }
-      }
+  }
+  if constexpr (!LIST) {
+    if (lane == 0) {
+      s_qn[2 * wave] = wn;   // (the queues are idle now: their scratch words carry the list lengths to the exact stage)
+      if (wovf) s_cnt[3] = 1;
+      atomicAdd(&s_cnt[0], wn);
     }
     __syncthreads();
+    gmax_run = fmax(gmax_run, __longlong_as_double((long long)s_thr[0]));   // best pair score of the scan
   }
 
   MFX_STAMP(6);
@@ -802,15 +860,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   }
   // ---- exact re-evaluation (reference arithmetic and summation order) of everything short-listed
   const double thr_final = gmax_run - eps_abs;
-  const int nappend = s_cnt[0], nfam_app = s_cnt[1];
-  const int ncand = nappend > MFX_XMAXC ? MFX_XMAXC : nappend;
+  const int ncand = s_cnt[0], nfam_app = s_cnt[1];   // short-listed (pair, tuple) entries of all waves; family items
   // (a voxel in which no support scores above zero keeps the reference's initial state: nothing to evaluate)
   const bool nothing = !(gmax_run > 0.0);
   if (tid == 0 && a.ovf_count) {   // diagnostics: short-listed pairs and family items of the launch
     atomicAdd(a.ovf_count + 2, LIST ? a.xl_cnt[blockIdx.x] : ncand);
     atomicAdd(a.ovf_count + 3, nfam_app);
   }
-  const bool exhaustive = !nothing && (a.maxc == 0 || nappend > a.maxc || nfam_app > MFX_XFAM);   // workgroup-uniform
+  const bool exhaustive = !nothing && (a.maxc == 0 || s_cnt[3] != 0 || nfam_app > MFX_XFAM);   // workgroup-uniform
   __syncthreads();
   if (exhaustive) {
     // The short list overflowed: nothing above can be trusted.  Last resort, exact by construction: every tuple
@@ -823,20 +880,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       consider((int)(pr / N), (int)(pr % N), t);
     }
   } else if (!nothing) {
-    // short-listed pairs, every extra tuple (they tie when the extra column is inactive)
-    for (int q = tid; q < ncand * ntup; q += WG) {
-      const int c = q / ntup, t = q - c * ntup;
-      if (s_cand[c].score >= thr_final) consider(s_cand[c].i, s_cand[c].j, t);
+    // short-listed pairs, every extra tuple (they tie when the extra column is inactive).  A pair is listed once per
+    // tuple that scored near the optimum: the later copies are struck out first.
+    if constexpr (!LIST) {
+      for (int c = tid; c < NW * WCAP; c += WG) {
+        const int w = c / WCAP, k = c - w * WCAP;
+        if (k < s_qn[2 * w] && s_cand[c].score >= thr_final) {
+          bool dup = false;
+          for (int c2 = 0; c2 < c && !dup; ++c2) {
+            const int w2 = c2 / WCAP;
+            dup = (c2 - w2 * WCAP) < s_qn[2 * w2] && s_cand[c2].i == s_cand[c].i && s_cand[c2].j == s_cand[c].j && s_cand[c2].score >= thr_final;
+          }
+          if (dup) s_cand[c].score = -2.0;
+        }
+      }
+      __syncthreads();
+      for (int q = tid; q < NW * WCAP * ntup; q += WG) {
+        const int c = q / ntup, t = q - c * ntup;
+        const int w = c / WCAP, k = c - w * WCAP;
+        if (k < s_qn[2 * w] && s_cand[c].score >= thr_final) consider(s_cand[c].i, s_cand[c].j, t);
+      }
     }
     for (int f = 0; f < nfam_app; ++f) {   // workgroup-uniform loop
       const int type = s_fam[f].type, fa = s_fam[f].a, ft = s_fam[f].t;
       if (type == 1) { for (int n = tid; n < N; n += WG) consider(fa, n, ft); }
       else if (type == 2) { for (int n = tid; n < N; n += WG) consider(n, fa, ft); }
       else if (type == 3) { if (tid == 0) consider(0, 0, ft); }
-      else {   // 4: row fa, columns ft, ft + 16, ...: the (lane,row) slot of the scan, all extra tuples
-        const int ncol = (N - ft + 15) / 16;
-        for (int q = tid; q < ncol * ntup; q += WG) consider(fa, ft + 16 * (q / ntup), q % ntup);
-      }
     }
   }
   // lexicographic (res, key) minimum over the workgroup, folded into the reference's initial state (w = 0, indices 0,

@@ -14,7 +14,23 @@ static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf, 
                (4 * MFX_XS + 2) + (size_t)nw * 16 + 2 * 16 + 2;                    // s_tc, s_rowf, s_colf, s_thr
   dbl += (size_t)M * NX;                                                           // s_xx
   return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(FamX) * MFX_XFAM + sizeof(ProjC) * ((size_t)nw * 16 + 2 * 16) * ntup +
-         sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4);
+         sizeof(int) * (2 * MP + (bracket ? 2 * MP : 0) + 4 + 2 * nw) + sizeof(QItem) * (size_t)nw * MFX_XQ;
+}
+
+// LDS plan of a launch: the extra columns in LDS when the 160 KB allow it, else read from global memory
+static int k2x_lds_plan(FitK2XArgs& a, int ksteps, bool bracket, int nw, int nbuf, int ntup, size_t* lds) {
+  const size_t cap = 160 * 1024;
+  a.xx_in_lds = 1;
+  *lds = k2x_lds_bytes(ksteps, bracket, a.T.ldn, nw, nbuf, ntup, a.P.M, a.X.NX);
+  if (*lds <= cap) return MFX_OK;
+  a.xx_in_lds = 0;
+  *lds = k2x_lds_bytes(ksteps, bracket, a.T.ldn, nw, nbuf, ntup, 0, 0);
+  if (*lds <= cap) return MFX_OK;
+  return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", *lds, a.T.N);
+}
+static bool k2x_fits(const FitK2XArgs& a, int ksteps, bool bracket, int nw, int nbuf) {
+  const int ntup = (a.X.has_csf && a.X.E > 0) ? a.X.E : a.X.NX;
+  return k2x_lds_bytes(ksteps, bracket, a.T.ldn, nw, nbuf, ntup, 0, 0) <= 160 * 1024;
 }
 
 template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
@@ -23,10 +39,8 @@ static int launch_k2x_t(FitK2XArgs a, int nvox, hipStream_t st) {
   const int ntup = (a.X.has_csf && a.X.E > 0) ? a.X.E : a.X.NX;   // extra tuples per atom pair (fit_k2x.hip)
   if (a.X.NX > 15) return mfx_fail(MFX_ERR_UNSUPPORTED, "two-fascicle classes support at most 15 CSF+EAR columns (got %d)", a.X.NX);
   if (16 * (ntup + 1) > NW * 64) return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel: %d extra tuples exceed this protocol length's limit of %d", ntup, NW * 4 - 1);
-  size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, a.P.M, a.X.NX);
-  a.xx_in_lds = 1;
-  if (lds > 160 * 1024) { lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, 0, 0); a.xx_in_lds = 0; }   // extras stay in global memory
-  if (lds > 160 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
+  size_t lds = 0;
+  if (int rc = k2x_lds_plan(a, KSTEPS, BRACKET, NW, NBUF, ntup, &lds)) return rc;
   auto kern = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // per-workgroup scratch slab: launch in chunks so the slab stays modest
@@ -61,10 +75,8 @@ template <int KSTEPS, bool BRACKET, int NW = 8, int NBUF = 2>
 static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   MfxThread& T = mfx_thread();
   const int ntup = 1;
-  size_t lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, a.P.M, a.X.NX);
-  a.xx_in_lds = 1;
-  if (lds > 160 * 1024) { lds = k2x_lds_bytes(KSTEPS, BRACKET, a.T.ldn, NW, NBUF, ntup, 0, 0); a.xx_in_lds = 0; }
-  if (lds > 160 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2+extras kernel needs %zu B of LDS: N=%d too large", lds, a.T.N);
+  size_t lds = 0;
+  if (int rc = k2x_lds_plan(a, KSTEPS, BRACKET, NW, NBUF, ntup, &lds)) return rc;
   auto kern_list = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF, true>;
   auto kern_full = mfx_fit_k2x_kernel<KSTEPS, BRACKET, NW, NBUF, false>;
   HIPCHK(hipFuncSetAttribute((const void*)kern_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -138,9 +150,11 @@ int mfx_launch_k2x(const FitK2XArgs& a, int nvox, hipStream_t st) {
       return br ? launch_k2sx_pipeline<140, true, 4, 1>(a, nvox, st) : launch_k2sx_pipeline<140, false, 4, 1>(a, nvox, st);
     }
   }
-  if (M <= 64) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
-  if (M <= 200) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
-  if (M <= 400) return br ? launch_k2x_t<100, true, 4, 1>(a, nvox, st) : launch_k2x_t<100, false, 4, 1>(a, nvox, st);
+  // (a variant whose LDS does not fit - many atoms, many extra columns - hands over to the next: the four-wave variants
+  // hold one chunk buffer instead of two; padded measurement rows are zero rows)
+  if (M <= 64 && k2x_fits(a, 16, br, 8, 2)) return br ? launch_k2x_t<16, true>(a, nvox, st) : launch_k2x_t<16, false>(a, nvox, st);
+  if (M <= 200 && k2x_fits(a, 50, br, 8, 2)) return br ? launch_k2x_t<50, true>(a, nvox, st) : launch_k2x_t<50, false>(a, nvox, st);
+  if (M <= 400 && k2x_fits(a, 100, br, 4, 1)) return br ? launch_k2x_t<100, true, 4, 1>(a, nvox, st) : launch_k2x_t<100, false, 4, 1>(a, nvox, st);
   if (M <= 560) return br ? launch_k2x_t<140, true, 4, 1>(a, nvox, st) : launch_k2x_t<140, false, 4, 1>(a, nvox, st);
   return mfx_fail(MFX_ERR_UNSUPPORTED, "K=2 fused kernels support M <= 560 (got %d)", M);
 }

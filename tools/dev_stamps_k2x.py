@@ -41,7 +41,11 @@ if WMODE:
     for w, off in (("wave 0", 0), ("last wave", 8)):
         print("chunk 10 of round 1, %s (median cycles):" % w)
         for k, nm in enumerate(["gen_load (issue)", "MFMA loop", "gen_store", "filter + scoring", "barrier wait"]):
-            print("   %-20s %8.0f" % (nm, d(off + k, off + k + 1)))
+            print("   %-20s %8.0f   (mean %8.0f)" % (nm, d(off + k, off + k + 1), np.mean(s[:, off + k + 1] - s[:, off + k])))
+        ok = s[:, off + 6] > 0
+        print("   of it the filter    %8.0f   (mean %8.0f)" % (np.median(s[ok, off + 6] - s[ok, off + 3]), np.mean(s[ok, off + 6] - s[ok, off + 3])))
+        print("   queue + scoring     %8.0f   (mean %8.0f)" % (np.median(s[ok, off + 4] - s[ok, off + 6]), np.mean(s[ok, off + 4] - s[ok, off + 6])))
+        print("   tuples in the wave's queue: median %d, mean %.1f, p90 %d, max %d" % (np.median(s[:, off + 7]), s[:, off + 7].mean(), np.percentile(s[:, off + 7], 90), s[:, off + 7].max()))
     sys.exit(0)
 tot = d(0, 9)
 print("class csf=%d ear=%d: total cycles per voxel (median) %.0f" % (c, e, tot))

@@ -4,6 +4,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from microstructure_fingerprinting_amd import _lib as L, engine, synth, mf_utils as mfu
+if os.environ.get("MFX_DEV_LIB"):   # a diagnostic build of the library (file name inside the package directory)
+    L.LIB_PATH = os.path.join(ROOT, "microstructure_fingerprinting_amd", os.environ["MFX_DEV_LIB"])
 
 def run(name, cfg, V, K, c, e, E=10, N=None, bracket=False):
     sch, dic, rng = synth.make_model(cfg, N=N)
