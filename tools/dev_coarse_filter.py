@@ -65,10 +65,21 @@ for v in range(V):
     coarse = (Pm[0][:, None] * Pm[1][None, :] - Qm[0][:, None] * Qm[1][None, :] - (accf - Um[0][:, None] * Um[1][None, :])) >= 0
     assert bool((coarse | ~passt).all())
     nt = (N + 15) // 16
+    grp = {}
+    for G in (2, 5):   # the same first test per GROUP of G adjacent tuples: share of (cell, group) combinations that pass
+        tot = 0
+        for g0 in range(0, E, G):
+            sl = slice(g0, g0 + G)
+            Pg = [p[sl].max(0).values for p in Pn]; Qg = [q[sl].min(0).values for q in Qn]; Ug = [u[sl].abs().max(0).values for u in U]
+            cg = (Pg[0][:, None] * Pg[1][None, :] - Qg[0][:, None] * Qg[1][None, :] - (accf - Ug[0][:, None] * Ug[1][None, :])) >= 0
+            pp = torch.zeros((nt * 16, nt * 16), dtype=torch.bool, device=dev); pp[:N, :N] = cg
+            tot += int(pp.view(nt, 16, nt, 16).any(3).any(1).sum())
+        grp[G] = tot / (nt ** 2 * (E // G))
     def cells(m):
         p = torch.zeros((nt * 16, nt * 16), dtype=torch.bool, device=dev); p[:N, :N] = m
         return int(p.view(nt, 16, nt, 16).any(3).any(1).sum())
     rows.append((npass / (N * N * E), float(passt.float().mean()), float(coarse.float().mean()), cells(passt) / nt ** 2, cells(coarse) / nt ** 2))
-    print("voxel %2d: tuples passing %.4f, pairs with a passing tuple %.4f, pairs passing the first test %.4f | cells: real %.3f, first test %.3f" % ((v,) + rows[-1]), flush=True)
+    rows[-1] = rows[-1] + (grp[2], grp[5])
+    print("voxel %2d: tuples passing %.4f, pairs with a passing tuple %.4f, pairs passing the first test %.4f | cells: real %.3f, first test %.3f | (cell, group) passing: groups of 2 %.3f, of 5 %.3f" % ((v,) + rows[-1]), flush=True)
 r = np.array(rows)
-print("median / mean over %d voxels: cells that need the tuple loop: really %.3f / %.3f, by the first test %.3f / %.3f" % (V, np.median(r[:, 3]), r[:, 3].mean(), np.median(r[:, 4]), r[:, 4].mean()))
+print("median / mean over %d voxels: cells that need the tuple loop: really %.3f / %.3f, by the first test %.3f / %.3f; (cell, group) combinations passing a per-group first test: groups of 2 %.3f / %.3f, of 5 %.3f / %.3f" % (V, np.median(r[:, 3]), r[:, 3].mean(), np.median(r[:, 4]), r[:, 4].mean(), np.median(r[:, 5]), r[:, 5].mean(), np.median(r[:, 6]), r[:, 6].mean()))
