@@ -79,9 +79,9 @@ struct DevMem {
 };
 // Stream-ordered scratch memory comes from ONE library-owned memory pool per device whose release threshold is
 // unlimited: what a call allocates stays mapped for the next one.  (HIP's default pool hands its memory back to the
-// driver at every stream synchronisation and maps it again at the next call; on the MI355X box of round 2 kernels then
-// read stale data through the re-mapped addresses on some XCDs - repeated mfx_fit_batch calls on identical inputs
-// returned different rows for blocks of voxels)  mfx_scratch_alloc fails loudly if the pool cannot
+// driver at every stream synchronisation and maps it again at the next call; on the MI355X boxes of round 2 the first
+// workgroups of the next kernel then saw their own writes to such memory replaced by zeros - tools/micro/
+// mempool_remap.hip reproduces it without this library)  mfx_scratch_alloc fails loudly if the pool cannot
 // be created.  MFX_POISON=<byte>: every scratch allocation is filled with that byte before use (developer check for
 // reads of uninitialised scratch memory).
 hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s);
