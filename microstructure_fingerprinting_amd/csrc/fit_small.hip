@@ -13,8 +13,11 @@
 #include "mfx_device.h"
 #include "nnls_small.h"
 
+#include <type_traits>
+
 #define MFX_SWG 256
 #define MFX_NXMAX 16
+#define MFX_SLIST 1024   // [N,1,E]: tuples the exact pass takes from its LDS list (more: the pass scans the atoms' flags)
 
 struct ExtrasDev {
   int NX;             // active extra columns of this voxel class (csf_i + ear_i * E), <= MFX_NXMAX
@@ -88,8 +91,11 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
   double* s_res = s_misc + 8;         // [SWG]
   double* s_w = s_res + MFX_SWG;      // [SWG][3]
   long* s_key = (long*)(s_w + 3 * MFX_SWG);  // [SWG]
-  int* s_r0 = (int*)(s_key + MFX_SWG);       // [M]
+  double* s_amin = (double*)(s_key + MFX_SWG);   // [N] ([N,1,E] only) best ranking residual of each atom's tuples
+  int* s_r0 = (int*)(s_amin + N);            // [M]
   int* s_r1 = s_r0 + M;                      // [M]
+  int* s_list = s_r1 + M;                    // [SLIST] ([N,1,E]) tuples for the exact pass
+  int* s_cnt = s_list + MFX_SLIST;           // [1]
 
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   for (int m = tid; m < M; m += MFX_SWG) s_y[m] = yv[m];
@@ -134,48 +140,124 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
     if (res < bres || (res == bres && bkey >= 0 && key < bkey)) { bres = res; bkey = key; bw[0] = w0; bw[1] = w1; bw[2] = w2; }
   };
 
-  if (K == 1) {
-    for (int i = tid; i < N; i += MFX_SWG) {
-      double a11 = 0.0, Y1 = 0.0, a1x[MFX_NXMAX];
+  // column sums of one rotated atom, sequential over the rows (the reference's loops).  The extra columns go in groups
+  // of four with a compile-time count (a run-time column count costs a scalar branch per column and row: 4x the
+  // instructions); the values come through uniform (scalar) loads, columns beyond NX are multiplied by zero.
+  auto atom_stats_n = [&](auto ngc, int i, double& a11, double& Y1, double* a1x) {
+    constexpr int NE = decltype(ngc)::value * 4;
+    for (int m = 0; m < M; ++m) {
+      const double d = elem(m, i);
+      a11 += d * d;
+      Y1 += s_y[m] * d;
 #pragma unroll
-      for (int e = 0; e < MFX_NXMAX; ++e) a1x[e] = 0.0;
+      for (int e = 0; e < NE; ++e) {
+        const double xe = xx[(size_t)m * NX + (e < NX ? e : NX - 1)];
+        a1x[e] += d * (e < NX ? xe : 0.0);
+      }
+    }
+  };
+  auto atom_stats = [&](int i, double& a11, double& Y1, double* a1x) {
+    a11 = 0.0; Y1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MFX_NXMAX; ++e) a1x[e] = 0.0;
+    if (NX == 0) atom_stats_n(std::integral_constant<int, 0>{}, i, a11, Y1, a1x);
+    else if (NX <= 4) atom_stats_n(std::integral_constant<int, 1>{}, i, a11, Y1, a1x);
+    else if (NX <= 8) atom_stats_n(std::integral_constant<int, 2>{}, i, a11, Y1, a1x);
+    else if (NX <= 12) atom_stats_n(std::integral_constant<int, 3>{}, i, a11, Y1, a1x);
+    else atom_stats_n(std::integral_constant<int, 4>{}, i, a11, Y1, a1x);
+  };
+  if (K == 1 && Kp == 3) {
+    // [N,1,E]: i1 = atom, i2 = CSF (single), i3 = EAR atom, scan order i3 -> i1 -> i2.  The reference sums an explicit
+    // residual over the M rows for every tuple whose Cramer solution is positive - N E M table look-ups per voxel, ten
+    // times the rotation itself.  Two passes instead: every tuple is RANKED with the residual of the same weights from the
+    // Gram scalars (|w' G w - 2 w' b + y'y| differs from the explicit sum by its evaluation rounding only, not by the
+    // conditioning of the triple), then every tuple of every atom that comes within 1e-7 |y|^2 of the best ranking
+    // residual is evaluated in the reference's arithmetic and scan order - the winner and everything tying with it.
+    double rmin_t = y_sq;
+    for (int i = tid; i < N; i += MFX_SWG) {
+      double a11, Y1, a1x[MFX_NXMAX];
+      atom_stats(i, a11, Y1, a1x);
+      double amin = y_sq;
+#pragma unroll
+      for (int e = 0; e < MFX_NXMAX - 1; ++e)
+        if (e < E) {
+          const int ce = 1 + e;
+          const double g22 = Gxx[0], g23 = Gxx[ce], g33 = Gxx[ce * NX + ce], y2 = s_Yx[0], y3 = s_Yx[ce];
+          double w[3], r;
+          auto gram_res = [&](const double* ww) {
+            return y_sq + (ww[0] * (ww[0] * a11 + 2.0 * (ww[1] * a1x[0] + ww[2] * a1x[ce] - Y1)) +
+                           ww[1] * (ww[1] * g22 + 2.0 * (ww[2] * g23 - y2)) + ww[2] * (ww[2] * g33 - 2.0 * y3));
+          };
+          nnls3_cramer(y_sq, a11, a1x[0], a1x[ce], g22, g23, g33, Y1, y2, y3, gram_res, w, r);
+          amin = fmin(amin, r);
+        }
+      s_amin[i] = amin;
+      rmin_t = fmin(rmin_t, amin);
+    }
+    s_res[tid] = rmin_t;
+    __syncthreads();
+    for (int o = MFX_SWG / 2; o > 0; o >>= 1) {
+      if (tid < o) s_res[tid] = fmin(s_res[tid], s_res[tid + o]);
+      __syncthreads();
+    }
+    const double cut = s_res[0] + 1e-7 * y_sq;
+    if (tid == 0) s_cnt[0] = 0;
+    __syncthreads();   // s_res is reused below
+    // the tuples to evaluate exactly, dealt to the threads one by one (an atom's ten explicit residuals in the one thread
+    // that owns it kept the other 255 waiting)
+    for (int i = tid; i < N; i += MFX_SWG) {
+      if (!(s_amin[i] <= cut)) continue;
+      const int q0 = atomicAdd(&s_cnt[0], E);
+      for (int e = 0; e < E; ++e)
+        if (q0 + e < MFX_SLIST) s_list[q0 + e] = e * N + i;
+    }
+    __syncthreads();
+    const int nl = s_cnt[0];
+    auto exact_tuple = [&](int i, int e) {   // column sums of the atom with the two columns of the tuple, then the tuple
+      const int ce = 1 + e;
+      double a11 = 0.0, Y1 = 0.0, a1c = 0.0, a1e = 0.0;
       for (int m = 0; m < M; ++m) {
         const double d = elem(m, i);
         a11 += d * d;
         Y1 += s_y[m] * d;
-#pragma unroll
-        for (int e = 0; e < MFX_NXMAX; ++e)
-          if (e < NX) a1x[e] += d * xx[(size_t)m * NX + e];
+        a1c += d * xx[(size_t)m * NX];
+        a1e += d * xx[(size_t)m * NX + ce];
       }
+      double w[3], r;
+      auto explicit_res = [&](const double* ww) {
+        double rr = 0.0;
+        for (int m = 0; m < M; ++m) {
+          const double t = (ww[0] * elem(m, i) + ww[1] * xx[(size_t)m * NX] + ww[2] * xx[(size_t)m * NX + ce] - s_y[m]);
+          rr += t * t;
+        }
+        return rr;
+      };
+      nnls3_cramer(y_sq, a11, a1c, a1e, Gxx[0], Gxx[ce], Gxx[ce * NX + ce], Y1, s_Yx[0], s_Yx[ce], explicit_res, w, r);
+      consider(r, (long)e * N + i, w[0], w[1], w[2]);
+    };
+    if (nl <= MFX_SLIST) {
+      for (int q = tid; q < nl; q += MFX_SWG) exact_tuple(s_list[q] % N, s_list[q] / N);
+    } else {   // (a voxel in which most atoms tie, e.g. no fascicle signal at all: every tuple of the qualifying atoms)
+      for (int q = tid; q < N * E; q += MFX_SWG) {
+        const int i = q % N;
+        if (s_amin[i] <= cut) exact_tuple(i, q / N);
+      }
+    }
+  } else if (K == 1) {
+    for (int i = tid; i < N; i += MFX_SWG) {
+      double a11, Y1, a1x[MFX_NXMAX];
+      atom_stats(i, a11, Y1, a1x);
       if (Kp == 1) {
         double w, r;
         nnls1_exact(y_sq, a11, Y1, w, r);
         consider(r, i, w, 0.0, 0.0);
-      } else if (Kp == 2) {  // [N,1] or [N,E]: i1 = atom (outer), i2 = extra column (inner)
+      } else {  // Kp == 2: [N,1] or [N,E]: i1 = atom (outer), i2 = extra column (inner)
 #pragma unroll
         for (int e = 0; e < MFX_NXMAX; ++e)
           if (e < NX) {
             double w0, w1, r;
             nnls2_exact(y_sq, a11, a1x[e], Gxx[e * NX + e], Y1, s_Yx[e], w0, w1, r);
             consider(r, (long)i * NX + e, w0, w1, 0.0);
-          }
-      } else {  // [N,1,E]: i1 = atom, i2 = CSF (single), i3 = EAR atom, scan order i3 -> i1 -> i2
-#pragma unroll
-        for (int e = 0; e < MFX_NXMAX - 1; ++e)
-          if (e < E) {
-            const int ce = 1 + e;
-            double w[3], r;
-            auto explicit_res = [&](const double* ww) {
-              double rr = 0.0;
-              for (int m = 0; m < M; ++m) {
-                const double t = (ww[0] * elem(m, i) + ww[1] * xx[(size_t)m * NX] + ww[2] * xx[(size_t)m * NX + ce] - s_y[m]);
-                rr += t * t;
-              }
-              return rr;
-            };
-            nnls3_cramer(y_sq, a11, a1x[0], a1x[ce], Gxx[0], Gxx[ce], Gxx[ce * NX + ce], Y1, s_Yx[0], s_Yx[ce],
-                         explicit_res, w, r);
-            consider(r, (long)e * N + i, w[0], w[1], w[2]);
           }
       }
     }
