@@ -820,6 +820,76 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     const double xmrg = a.xl_mrg[blockIdx.x];
     bool beaten = false;
     double lbs = 0.0;   // best one-atom support among the listed single atoms
+    if (Kp == 3 && NX == 1) {
+      // The screening pipeline's class ([N, N, 1]).  A thread that walks its pair's 2 x M rows through the table alone pays
+      // an L2 round trip per row block and sums seven products per row in one instruction stream (156 k of a voxel's
+      // 200 k cycles).  Instead, per batch of PB listed entries: the whole workgroup stages the rotated columns in the
+      // (idle) chunk buffers; EIGHT lanes per pair take one of the reference's seven sequential sums each (the sums stay
+      // sequential over the rows, only different sums run side by side); lane 0 of the group solves the triple and sums
+      // the explicit residual from the staged columns.
+      constexpr int PB = NBUF * 8;   // listed entries per batch: two columns of MP rows each
+      double* s_sum = s_a1x;         // [PB][8] (the row staging of the scan is idle in list mode)
+      static_assert(PB * 8 <= NW * 16 * MFX_XS && PB * 8 <= WG, "list-mode batch");
+      for (int c0 = 0; c0 < cnt; c0 += PB) {
+        const int nb = min(PB, cnt - c0);
+        for (int q = tid; q < nb * 2 * MP; q += WG) {
+          const int c = q / (2 * MP), r = q - c * (2 * MP), k = r / MP, m = r - k * MP;
+          const Cand e = lst[c0 + c];
+          const int n = k ? e.j : e.i;   // (negative: a single atom of the other dictionary)
+          sB[q] = (n >= 0 && m < M) ? elem(k, m, n & 0x3fffffff) : 0.0;
+        }
+        __syncthreads();
+        if (tid < nb * 8) {
+          const int c = tid >> 3, sl = tid & 7;
+          const Cand e = lst[c0 + c];
+          const double* d1s = sB + (size_t)c * (2 * MP);
+          const double* d2s = d1s + MP;
+          const bool pair = e.i >= 0 && e.j >= 0;
+          if (pair && sl < 7) {
+            // sum sl of mf_utils.py:548-553's Gram scalars: a11 a22 a12 y1 y2 a13 a23 (factor order as in consider())
+            const double* p = (sl == 1 || sl == 4 || sl == 6) ? d2s : ((sl == 3) ? s_y : d1s);
+            const double* q = (sl == 0) ? d1s : ((sl == 1 || sl == 2) ? d2s : ((sl == 3) ? d1s : ((sl == 4) ? s_y : xx)));
+            // (y1 += ym * d1, y2 += ym * d2: the products commute exactly)
+            double acc = 0.0;
+            for (int m = 0; m < M; ++m) acc += p[m] * q[m];   // (NX == 1: the extra column has stride 1)
+            s_sum[tid] = acc;
+          }
+          __builtin_amdgcn_wave_barrier();   // (a group sits inside one wave; its LDS operations execute in order)
+          if (sl == 0) {
+            if (pair) {
+              const int i = e.i, j = e.j & 0x3fffffff;
+              const double a11 = s_sum[tid], a22 = s_sum[tid + 1], a12 = s_sum[tid + 2], y1 = s_sum[tid + 3], y2 = s_sum[tid + 4],
+                           a13 = s_sum[tid + 5], a23 = s_sum[tid + 6];
+              double u[3], r;
+              auto explicit_res = [&](const double* ww) {
+                double rr = 0.0;
+                for (int m = 0; m < M; ++m) {
+                  const double tt = (ww[0] * d1s[m] + ww[1] * d2s[m] + ww[2] * xx[m] - s_y[m]);
+                  rr += tt * tt;
+                }
+                return rr;
+              };
+              nnls3_cramer(y_sq, a11, a12, a13, a22, a23, s_Gxx[0], y1, y2, s_Yx[0], explicit_res, u, r);
+              const long k = (long)i * N + j;   // scan order of _3 with one extra tuple: i1 -> i2
+              if (r < res || (r == res && k < key)) { res = r; key = k; w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = 0.0; }
+              beaten |= (y_sq - r) > e.score + 1.25 * xmrg;
+            } else {   // a single atom of dictionary 0 (j < 0) or 1 (i < 0): its best one-atom support (ranking only)
+              const double* ds = (e.i < 0) ? d2s : d1s;
+              double a2 = 0.0, ay = 0.0, ax0 = 0.0;
+              for (int m = 0; m < M; ++m) {
+                const double d = ds[m];
+                a2 = fma(d, d, a2);
+                ay = fma(s_y[m], d, ay);
+                ax0 = fma(d, xx[m], ax0);
+              }
+              const double ax1[1] = {ax0};
+              lbs = fmax(lbs, atom_best(a2, ay, ax1, 0));
+            }
+          }
+        }
+        __syncthreads();   // the next batch overwrites the staged columns
+      }
+    } else {
     for (int q = tid; q < cnt * ntup; q += WG) {
       const int c = q / ntup, t = q - c * ntup;
       const Cand e = lst[c];
@@ -833,6 +903,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         for (int tt = 0; tt < ntup; ++tt) lbs = fmax(lbs, atom_best(a2, ay, ax, tt));
       }
     }
+    }
+    MFX_STAMP(12);   // (diagnostic builds: listed pairs and single atoms evaluated)
     double lb = fmax((key >= 0) ? y_sq - res : 0.0, lbs);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lb = fmax(lb, __shfl_xor(lb, o));
@@ -846,7 +918,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       atomicAdd(a.fb_count + 1, 1);
     }
     __syncthreads();   // s_red is free again
+    MFX_STAMP(13);
     family_detection();
+    MFX_STAMP(14);
     // more families than the exact stage takes (a voxel whose signal is mostly the extra column: every atom's relaxed
     // score reaches the threshold): not this kernel's exhaustive pass over all tuples - the plain kernel has its own scan
     // and decides what is really needed

@@ -52,5 +52,8 @@ print("class csf=%d ear=%d: total cycles per voxel (median) %.0f" % (c, e, tot))
 for nm, a_, b_ in [("phase 0", 0, 1), ("phase 1 statistics", 1, 2), ("round 0: A operand + row constants", 2, 3), ("round 0: first chunk", 3, 4),
                    ("round 0: chunk loop", 4, 5), ("all rounds", 2, 6), ("family detection", 6, 7), ("exact stage", 7, 8), ("outputs", 8, 9)]:
     print("  %-36s %10.0f  %5.1f %%" % (nm, d(a_, b_), 100 * d(a_, b_) / tot))
+if s[:, 12].any():   # list mode (the class runs on the screening pipeline): the exact stage in detail
+    for nm, a_, b_ in [("  list: pairs + single atoms exact", 7, 12), ("  list: reduction", 12, 13), ("  list: family detection", 13, 14), ("  list: families exact + argmin", 14, 8)]:
+        print("  %-36s %10.0f  %5.1f %%   (mean %.0f)" % (nm, d(a_, b_), 100 * d(a_, b_) / tot, np.mean(s[:, b_] - s[:, a_])))
 print("tuples passing the filter per voxel: median %d, mean %.0f, p90 %d, max %d (of %d)" % (np.median(s[:, 10]), s[:, 10].mean(), np.percentile(s[:, 10], 90), s[:, 10].max(), N * N * (E if e else 1)))
 print("(wave, row group) scoring passes per voxel: median %d, mean %.0f (of %d wave tiles x 4)" % (np.median(s[:, 11]), s[:, 11].mean(), 49 * 49))
