@@ -45,3 +45,14 @@ for it in range(3):
     t1 = time.time()
     print("engine.fit_batch (mfx_fit_batch_rows) on %d voxels: %.1f ms" % (V, (t1 - t0) * 1e3), flush=True)
 print("mean MSE %.1f (noise variance %.1f)" % (fit.MSE.mean(), (500 / 30) ** 2))
+# a mixed ROI: 40 % of the voxels with one fascicle, 60 % with two; 40 % carry the CSF flag (five voxel classes per chunk)
+Km = np.where(rng.random(V) < 0.4, 1, 2).astype(np.int32)
+csfm = rng.random(V) < 0.4
+gam = mfu.get_gyromagnetic_ratio('H')
+bval = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-bval * 3e-9)
+for it in range(3):
+    t0 = time.time()
+    engine.fit_batch(plan, Yh, Km, csfm, None, peaks, 2, True, False, sig_csf)
+    t1 = time.time()
+    print("mixed ROI (K = 1 / 2, with / without CSF) on %d voxels: %.1f ms -> %.0f voxels/s; counters %s" % (V, (t1 - t0) * 1e3, V / (t1 - t0), [mf._lib.lib().mfx_debug_last_counter(q) for q in range(6)]), flush=True)
