@@ -664,15 +664,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
             // raise the threshold with the best SCORE of this wave instruction first (an interval bound is not
             // a score and never raises it), then append only what still reaches it: no burst of stale entries
             bool feas = hit;
+            double q1x = 0.0, q2x = 0.0;   // (XC) u / |d'| of the two atoms
             if constexpr (XC) {
               // a relaxed score may raise the threshold only if it is the score of a feasible support: x's weight
               // w_x = yx - w1 u1 - w2 u2, w_i = e_i / (den |d_i'|), clearly non-negative (e carries an error <= etol,
               // u/|d'| <= 4)
-              const double q1 = (double)s_uf[i] * mfx_rcp_nr(fmax((double)s_cs[i], 1e-300));
-              const double q2 = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
-              feas = hit && (fma(-e2, q2, fma(-e1, q1, yx * den)) >= 8.0 * etol);
+              q1x = (double)s_uf[i] * mfx_rcp_nr(fmax((double)s_cs[i], 1e-300));
+              q2x = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
+              feas = hit && (fma(-e2, q2x, fma(-e1, q1x, yx * den)) >= 8.0 * etol);
             }
             double sraise = feas ? S : 0.0;
+            double slist = S;   // what the pair is listed with: an upper bound of the best score of its supports with BOTH atoms
             if constexpr (XC) {
               // x would get a negative weight: the pair's PLAIN two-atom score (x left out) is feasible and raises the
               // threshold instead - without it a voxel with no x signal never leaves the single-atom threshold, floods
@@ -687,6 +689,17 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
                 const double f1 = fma(-c0, w2, w1), f2 = fma(-c0, w1, w2), den0 = fma(-c0, c0, 1.0);
                 const bool ok0 = hit && !feas && (f1 > etol) && (f2 > etol) && (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
                 if (ok0) sraise = fma(w2, f2, w1 * f1) * mfx_rcp_nr(den0) - yx * yx;
+                // A pair whose relaxed optimum CLEARLY gives x a negative weight (both atoms clearly active in it) has x
+                // inactive in its NNLS optimum: that optimum is the plain two-atom problem's.  Listed with the plain score
+                // then, or - one atom clearly inactive there - not at all (supports with one atom are the list kernel's
+                // own).  Without this a flagged voxel WITHOUT x signal lists every pair its loose relaxed bound lets
+                // through: 17 % of such voxels overflowed their list and went to the FP64 kernel.
+                const bool xneg = hit && (e1 > etol) && (e2 > etol) && (fma(-e2, q2x, fma(-e1, q1x, yx * den)) <= -8.0 * etol) &&
+                                  (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
+                if (xneg) {
+                  if (ok0) slist = sraise + mrg;
+                  else if (f1 < -etol || f2 < -etol) slist = -1.0;
+                }
               }
             }
             const double smax = mfx_wave_max_down(fmax(sraise, 0.0));
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
               thr = smax - 2.0 * mrg;
               if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
             }
-            if ((hit | near) && S >= thr) push(S, i, hit ? j : (j | MFX_S_BOUND));
+            if ((hit | near) && slist >= thr) push(slist, i, hit ? j : (j | MFX_S_BOUND));
 #ifdef MFX_STAMPS_SCAN
             if (a.stamps && round == 0 && dbg_calls == 1 && wave == 0 && lane == 0) {
               unsigned long long* st = a.stamps + (size_t)blockIdx.x * 16;

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
             S = (dlo > 0.0 && c > -0.5) ? fmin(fma(z2, z2, u1 * u1 / dlo), fma(z1, z1, u2 * u2 / dlo)) + mrg : 1e300;
           }
           double sraise = hit ? S : 0.0;
+          double slist = S;
           if constexpr (XC) {   // see fit_k2s.hip: only feasible scores raise the threshold
             const double q1 = (double)s_uf[i] * mfx_rcp_nr(fmax((double)s_cs[i], 1e-300));
             const double q2 = (double)s_uf[NP + j] * mfx_rcp_nr(fmax(n2d, 1e-300));
@@ -515,6 +516,13 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
               const double f1 = fma(-c0, w2, w1), f2 = fma(-c0, w1, w2), den0 = fma(-c0, c0, 1.0);
               const bool ok0 = hit && !feas && (f1 > etol) && (f2 > etol) && (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
               if (ok0) sraise = fma(w2, f2, w1 * f1) * mfx_rcp_nr(den0) - yx * yx;
+              // (fit_k2s.hip: x clearly inactive in the pair's optimum - listed with its plain score, or not at all)
+              const bool xneg = hit && (e1 > etol) && (e2 > etol) && (fma(-e2, q2, fma(-e1, q1, yx * den)) <= -8.0 * etol) &&
+                                (den0 >= MFX_S_DENMIN) && (c0 >= 0.0) && (m1 > 0.0) && (m2 > 0.0);
+              if (xneg) {
+                if (ok0) slist = sraise + mrg;
+                else if (f1 < -etol || f2 < -etol) slist = -1.0;
+              }
             }
           }
           const double smax = wave_max(fmax(sraise, 0.0));
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
             thr = smax - 2.0 * mrg;
             if (lane == 0) atomicMax(&s_thr[0], mfx_nonneg_bits(thr));
           }
-          if ((hit | near) && S >= thr) push(S, i, hit ? j : (j | MFX_S_BOUND));
+          if ((hit | near) && slist >= thr) push(slist, i, hit ? j : (j | MFX_S_BOUND));
         }
       }
     };
