@@ -12,7 +12,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,42 +42,96 @@ int mfx_fail(int code, const char* fmt, ...) {
 }
 #define fail mfx_fail
 
-// ---- scratch pool (mfx_host.h): one per device, created at first use, never trimmed
 namespace {
-constexpr int MFX_MAXDEV = 64;
-std::mutex g_pool_mutex;
-hipMemPool_t g_pool[MFX_MAXDEV] = {};
+struct HostTrace {   // MFX_HOST_TRACE=1: stage times of mfx_fit_batch on stderr (developer diagnostics)
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  HostTrace() : on(std::getenv("MFX_HOST_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) const {
+    if (on) std::fprintf(stderr, "[mfx_fit_batch] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+  }
+};
+}  // namespace
+
+// ---- scratch arenas (mfx_host.h)
+namespace {
 int poison_byte() {
   static const int b = [] { const char* e = std::getenv("MFX_POISON"); return e ? (std::atoi(e) & 0xff) : -1; }();
   return b;
 }
+constexpr size_t ARENA_ALIGN = 256;
+constexpr size_t ARENA_MAX = 8;   // arenas a thread keeps (least recently used one goes)
+void arena_drop(MfxThread::Arena& A) {   // (the owner has made sure nothing on the stream still uses the blocks)
+  for (void* b : A.blocks) (void)hipFree(b);
+  A.blocks.clear(); A.sizes.clear(); A.cur = 0; A.off = 0;
+}
 }  // namespace
 hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s) {
+  MfxThread& T = mfx_thread();
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= MFX_MAXDEV) return hipErrorInvalidDevice;
-  hipMemPool_t pool;
-  {
-    std::lock_guard<std::mutex> g(g_pool_mutex);
-    if (!g_pool[dev]) {
-      hipMemPoolProps props{};
-      props.allocType = hipMemAllocationTypePinned;
-      props.handleTypes = hipMemHandleTypeNone;
-      props.location.type = hipMemLocationTypeDevice;
-      props.location.id = dev;
-      hipMemPool_t np = nullptr;
-      if ((e = hipMemPoolCreate(&np, &props)) != hipSuccess) return e;
-      uint64_t keep = UINT64_MAX;
-      if ((e = hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &keep)) != hipSuccess) { (void)hipMemPoolDestroy(np); return e; }
-      g_pool[dev] = np;
+  MfxThread::Arena* A = nullptr;
+  for (auto& a : T.arenas) if (a.device == dev && a.stream == s) { A = &a; break; }
+  if (!A) {
+    if (T.arenas.size() >= ARENA_MAX) {   // retire the least recently used idle arena (its stream may be gone: errors ignored)
+      size_t lru = T.arenas.size();
+      for (size_t q = 0; q < T.arenas.size(); ++q)
+        if (T.arenas[q].live == 0 && (lru == T.arenas.size() || T.arenas[q].used < T.arenas[lru].used)) lru = q;
+      if (lru == T.arenas.size()) return hipErrorOutOfMemory;
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      (void)hipSetDevice(T.arenas[lru].device);
+      (void)hipDeviceSynchronize();
+      arena_drop(T.arenas[lru]);
+      (void)hipSetDevice(cur);
+      T.arenas.erase(T.arenas.begin() + (long)lru);
     }
-    pool = g_pool[dev];
+    T.arenas.emplace_back();
+    A = &T.arenas.back();
+    A->device = dev; A->stream = s;
   }
-  if (!bytes) bytes = 8;
-  if ((e = hipMallocFromPoolAsync(p, bytes, pool, s)) != hipSuccess) return e;
-  if (poison_byte() >= 0) e = hipMemsetAsync(*p, poison_byte(), bytes, s);
-  return e;
+  A->used = ++T.arena_clock;
+  bytes = ((bytes ? bytes : 8) + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+  if (A->live == 0) {
+    A->cur = 0; A->off = 0;
+    if (A->blocks.size() > 1) {   // the arena grew during the last call: one block of the total size from now on
+      size_t total = 0;
+      for (size_t b : A->sizes) total += b;
+      if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+      arena_drop(*A);
+      void* nb = nullptr;
+      const size_t want = total + total / 4;
+      if ((e = hipMalloc(&nb, want)) != hipSuccess) return e;
+      A->blocks.push_back(nb); A->sizes.push_back(want);
+    }
+  }
+  while (A->cur < A->blocks.size() && A->off + bytes > A->sizes[A->cur]) { ++A->cur; A->off = 0; }
+  if (A->cur == A->blocks.size()) {   // a new block (hipMalloc synchronises the device; rare: sizes settle after a call or two)
+    const size_t last = A->sizes.empty() ? 0 : A->sizes.back();
+    const size_t want = std::max(bytes + bytes / 4, std::min<size_t>(2 * last, (size_t)1 << 30));
+    void* nb = nullptr;
+    if ((e = hipMalloc(&nb, want)) != hipSuccess) return e;
+    A->blocks.push_back(nb); A->sizes.push_back(want);
+    A->off = 0;
+  }
+  *p = (char*)A->blocks[A->cur] + A->off;
+  A->off += bytes;
+  ++A->live;
+  if (poison_byte() >= 0) return hipMemsetAsync(*p, poison_byte(), bytes, s);
+  return hipSuccess;
+}
+void mfx_scratch_free(void* p, hipStream_t s) {
+  (void)p;
+  MfxThread& T = mfx_thread();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  for (auto& a : T.arenas)
+    if (a.stream == s && a.device == dev && a.live > 0) {
+      bool mine = false;
+      for (size_t q = 0; q < a.blocks.size() && !mine; ++q) mine = (char*)p >= (char*)a.blocks[q] && (char*)p < (char*)a.blocks[q] + a.sizes[q];
+      if (mine) { --a.live; return; }
+    }
 }
 
 int mfx_prof_begin(hipStream_t st) {
@@ -547,8 +600,8 @@ struct ExtrasHost {
     return MFX_OK;
   }
   ~ExtrasHost() {
-    if (dx) (void)hipFreeAsync(dx, st);
-    if (dG) (void)hipFreeAsync(dG, st);
+    if (dx) mfx_scratch_free(dx, st);
+    if (dG) mfx_scratch_free(dG, st);
   }
 };
 
@@ -750,12 +803,18 @@ extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const dou
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large for one launch");
   if (int rc = require_device(p->t->device)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  HostTrace tr;
   if (int rc = mfx_fb_begin(st)) return rc;
+  tr.mark("dev: fb_begin");
   ExtrasHost X;
   if (int rc = X.build(p->d.M, csf_on ? 1 : 0, ear_on ? E : 0, d_sig_csf, d_sig_ear, st)) return rc;
+  tr.mark("dev: extras");
   if (int rc = fit_class_dev(p, d_Y, d_peaks, 3 * maxfasc, nullptr, nullptr, (int)V, maxfasc, csf_on ? 1 : 0, ear_on ? 1 : 0, X, maxfasc,
                              csf_on ? 1 : 0, ear_on ? 1 : 0, d_params_out, st)) return rc;
-  return mfx_fb_end(st);
+  tr.mark("dev: class launched (incl. scratch frees)");
+  const int rc_end = mfx_fb_end(st);
+  tr.mark("dev: fb_end");
+  return rc_end;
 }
 
 // ---- host-buffer voxel loop: pinned staging + chunked H2D on a copy stream overlapped with the kernels on a compute
@@ -806,13 +865,21 @@ static int pool_get(int slot, size_t bytes, void** out) {
 
 extern "C" int mfx_thread_release(void) {
   MfxThread& T = mfx_thread();
-  if (T.pipe_device < 0) return MFX_OK;
   int cur = 0;
   HIPCHK(hipGetDevice(&cur));
-  HIPCHK(hipSetDevice(T.pipe_device));
-  if (T.s_copy) (void)hipStreamSynchronize(T.s_copy);
-  if (T.s_comp) (void)hipStreamSynchronize(T.s_comp);
-  pipe_release(T);
+  if (T.pipe_device >= 0) {
+    HIPCHK(hipSetDevice(T.pipe_device));
+    if (T.s_copy) (void)hipStreamSynchronize(T.s_copy);
+    if (T.s_comp) (void)hipStreamSynchronize(T.s_comp);
+    pipe_release(T);
+  }
+  for (auto& a : T.arenas)   // idle scratch arenas of this thread (any device): wait for their work, then free the blocks
+    if (a.live == 0) {
+      (void)hipSetDevice(a.device);
+      (void)hipDeviceSynchronize();
+      arena_drop(a);
+    }
+  T.arenas.erase(std::remove_if(T.arenas.begin(), T.arenas.end(), [](const MfxThread::Arena& a) { return a.live == 0; }), T.arenas.end());
   HIPCHK(hipSetDevice(cur));
   return MFX_OK;
 }
@@ -821,14 +888,6 @@ namespace {
 struct PoolPtr {     // borrowed pointer into the thread's buffer pool
   void* p = nullptr;
   template <class U> U* as() const { return (U*)p; }
-};
-struct HostTrace {   // MFX_HOST_TRACE=1: stage times of mfx_fit_batch on stderr (developer diagnostics)
-  bool on;
-  std::chrono::steady_clock::time_point t0;
-  HostTrace() : on(std::getenv("MFX_HOST_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
-  void mark(const char* what) const {
-    if (on) std::fprintf(stderr, "[mfx_fit_batch] %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
-  }
 };
 }  // namespace
 

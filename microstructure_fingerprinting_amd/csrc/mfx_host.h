@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "fit_k2.hip"
 #include "fit_k2x.hip"
@@ -52,6 +53,18 @@ struct MfxThread {
   size_t pool_bytes[4] = {0, 0, 0, 0};
   // two internal streams of the voxel-by-voxel three-fascicle path (two voxels in flight: the launch gaps and the
   // tail of one voxel's kernels are covered by the other's), forked from and joined to the caller's stream by events
+  // scratch arenas (mfx_scratch_alloc): one per (device, stream) this thread has launched on
+  struct Arena {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::vector<void*> blocks;
+    std::vector<size_t> sizes;
+    size_t cur = 0, off = 0;   // block in use, bytes handed out of it
+    int live = 0;              // allocations not yet released
+    unsigned long long used = 0;   // (LRU stamp)
+  };
+  std::vector<Arena> arenas;
+  unsigned long long arena_clock = 0;
   hipStream_t s_lane[2] = {nullptr, nullptr};
   hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};   // [lane] join, [2] fork
   int lane_device = -1;
@@ -77,22 +90,25 @@ struct DevMem {
   void* release() { void* q = p; p = nullptr; return q; }
   template <class T> T* as() const { return (T*)p; }
 };
-// Stream-ordered scratch memory comes from ONE library-owned memory pool per device whose release threshold is
-// unlimited: what a call allocates stays mapped for the next one.  (HIP's default pool hands its memory back to the
-// driver at every stream synchronisation and maps it again at the next call; on the MI355X boxes of round 2 the first
-// workgroups of the next kernel then saw their own writes to such memory replaced by zeros - tools/micro/
-// mempool_remap.hip reproduces it without this library)  mfx_scratch_alloc fails loudly if the pool cannot
-// be created.  MFX_POISON=<byte>: every scratch allocation is filled with that byte before use (developer check for
-// reads of uninitialised scratch memory).
+// Scratch memory of a call (per-workgroup slabs, short lists, extra columns, Gram / candidate buffers) comes from an ARENA
+// per (host thread, stream): a few device blocks that are only ever grown, handed out by bumping an offset, and taken
+// back when the call's last StreamMem dies.  Calls on one stream execute in order, so the next call may reuse the
+// addresses while the previous one is still running; different streams and different host threads have their own arenas.
+// No HIP allocator call in the steady state: on the MI355X boxes of round 2 memory of HIP's DEFAULT stream-ordered pool
+// read back as zeros after being re-mapped (tools/micro/mempool_remap.hip), and hipFreeAsync - also into a
+// pool that keeps its memory - blocked the host for a kernel's duration from the second call in flight on.
+// MFX_POISON=<byte>: every scratch allocation is filled with that byte before use (developer check for reads of
+// uninitialised scratch memory).
 hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s);
-// stream-ordered allocation released (in stream order) on every exit path
+void mfx_scratch_free(void* p, hipStream_t s);
+// scratch allocation released on every exit path
 struct StreamMem {
   void* p = nullptr;
   hipStream_t s;
   explicit StreamMem(hipStream_t s_) : s(s_) {}
   StreamMem(const StreamMem&) = delete;
   StreamMem& operator=(const StreamMem&) = delete;
-  ~StreamMem() { if (p) (void)hipFreeAsync(p, s); }
+  ~StreamMem() { if (p) mfx_scratch_free(p, s); }
   hipError_t alloc(size_t bytes) { return mfx_scratch_alloc(&p, bytes, s); }
   template <class T> T* as() const { return (T*)p; }
 };
