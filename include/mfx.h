@@ -16,8 +16,10 @@
  *     device and never keeps a host pointer after return.  Opaque handles (mfx_tables,
  *     mfx_plan) are library-owned and freed by their *_destroy function.
  *   - "_dev" variants take DEVICE pointers (HBM-resident inputs/outputs, e.g. torch
- *     tensors' data_ptr) and a hipStream_t passed as void*; they only enqueue work on that
- *     stream (kernels, stream-ordered allocations) and never wait for the device.  What the
+ *     tensors' data_ptr) and a hipStream_t passed as void*; they only enqueue kernels on that
+ *     stream and do not wait for the device.  (Scratch memory comes from an arena the calling
+ *     thread keeps per stream; only while that arena still grows - the first call or two of a
+ *     given size - does a call allocate device memory, which synchronises.)  What the
  *     reference would raise from inside its voxel loop (a fascicle direction that is not a
  *     unit vector, mf_utils.py:1798-1802) cannot be returned by an asynchronous call: the
  *     kernels flag it in the plan's status word, mfx_plan_status() reports it.  Exception:
