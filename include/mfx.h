@@ -118,8 +118,9 @@ int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, 
                        const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out);
 /* mfx_fit_batch / mfx_fit_batch_rows keep their pinned staging buffers and device buffers (signals, directions,
  * parameters) in the calling thread's state between calls and only ever grow them, so that a volume fitted slab by
- * slab (the reference's loop, mf.py:976-1032) pays no allocation per call.  This returns them (after draining the
- * thread's streams); the next call allocates again.  No counterpart in the reference.                          */
+ * slab (the reference's loop, mf.py:976-1032) pays no allocation per call; every entry point's scratch memory lives
+ * in arenas the calling thread keeps per stream.  This returns all of it (after draining the thread's streams and
+ * the devices its arenas are on); the next call allocates again.  No counterpart in the reference.            */
 int mfx_thread_release(void);
 /* Device-resident variant: all pointers are device pointers.  Only the homogeneous class
  * "every voxel has K == maxfasc, csf == csf_on, ear == ear_on" is accepted (that is what a
