@@ -406,6 +406,45 @@ def test_dev_entry_point_does_not_block_with_calls_in_flight():
         assert torch.equal(o, alone)
 
 
+def test_two_host_threads_share_one_device():
+    """MFModel.fit(parallel=True) drives every GPU from its own host thread (mf.py: _fit_sharded); all library state that
+    is not owned by a handle is per thread (streams, staging and device buffers, scratch arenas, counters).  Two threads
+    fitting DIFFERENT mixed ROIs on the same device at the same time must each get what they get alone."""
+    import threading
+    from microstructure_fingerprinting_amd import engine, synth
+    N = 782
+    sch, ms, sig_csf, _, rng = _c4_model(N, 4)
+    plan = ms.plan_for(sch)
+    jobs = []
+    for seed, V in ((11, 3000), (12, 2200)):
+        r = np.random.default_rng(seed)
+        peaks, Y = _c2_like_voxels(r, plan, N, V)
+        K = np.where(r.random(V) < 0.3, 1, 2).astype(np.int32)
+        csf = r.random(V) < 0.5
+        Y = Y + 500.0 * 0.2 * csf[:, None] * sig_csf
+        jobs.append((plan, Y, K, csf, None, peaks, 2, True, False, sig_csf))
+    alone = [engine.fit_batch(*j) for j in jobs]
+    got = [[None] * 3, [None] * 3]
+    errs = []
+
+    def work(t):
+        try:
+            for it in range(3):
+                got[t][it] = engine.fit_batch(*jobs[t])
+        except Exception as e:   # noqa: BLE001 (reported below)
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(2):
+        for it in range(3):
+            assert np.array_equal(got[t][it], alone[t]), "thread %d, call %d" % (t, it + 1)
+
+
 def _c2_like_voxels(rng, plan, N, V):
     from microstructure_fingerprinting_amd import synth
     p1, p2 = synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)
