@@ -17,7 +17,8 @@
 
 #define MFX_SWG 256
 #define MFX_NXMAX 16
-#define MFX_SLIST 1024   // [N,1,E]: tuples the exact pass takes from its LDS list (more: the pass scans the atoms' flags)
+#define MFX_SATOMS 16   // [N,1,E]: atoms whose columns the exact pass stages in LDS (more: one lane per tuple, table look-ups)
+#define MFX_SLIST MFX_SATOMS
 
 struct ExtrasDev {
   int NX;             // active extra columns of this voxel class (csf_i + ear_i * E), <= MFX_NXMAX
@@ -92,13 +93,18 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
   double* s_w = s_res + MFX_SWG;      // [SWG][3]
   long* s_key = (long*)(s_w + 3 * MFX_SWG);  // [SWG]
   double* s_amin = (double*)(s_key + MFX_SWG);   // [N] ([N,1,E] only) best ranking residual of each atom's tuples
-  int* s_r0 = (int*)(s_amin + N);            // [M]
+  double* s_col = s_amin + N;                // [SATOMS][M] ([N,1,E]) staged rotated columns of the atoms of the exact pass
+  double* s_sum = s_col + MFX_SATOMS * M;    // [SATOMS][32] their column sums
+  double* s_xx = s_sum + MFX_SATOMS * 32;    // [M][NX] the extra columns (every row of every column sum reads them: broadcast
+                                             // LDS reads; as uniform GLOBAL loads they were 12 vector-memory instructions per row)
+  int* s_r0 = (int*)(s_xx + (size_t)M * NX);     // [M]
   int* s_r1 = s_r0 + M;                      // [M]
   int* s_list = s_r1 + M;                    // [SLIST] ([N,1,E]) tuples for the exact pass
   int* s_cnt = s_list + MFX_SLIST;           // [1]
 
   const double* __restrict__ yv = a.Y + (size_t)vox * M;
   for (int m = tid; m < M; m += MFX_SWG) s_y[m] = yv[m];
+  for (int q = tid; q < M * NX; q += MFX_SWG) s_xx[q] = a.X.x[q];
   if (K == 1) {
     const double* pk = a.peaks + (size_t)vox * a.peaks_ld;
     if (tid == 0) mfx_check_dir(a.P, pk, vox);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
     }
     return mfx_eval(tab, ldn, s_r0[m], s_t0[m], n);
   };
-  const double* __restrict__ xx = a.X.x;
+  const double* xx = s_xx;
   const double* __restrict__ Gxx = a.X.Gxx;
 
   // thread-local best in the reference's scan order; key < 0 = the reference's initial state
@@ -203,44 +209,71 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
     const double cut = s_res[0] + 1e-7 * y_sq;
     if (tid == 0) s_cnt[0] = 0;
     __syncthreads();   // s_res is reused below
-    // the tuples to evaluate exactly, dealt to the threads one by one (an atom's ten explicit residuals in the one thread
-    // that owns it kept the other 255 waiting)
+    // the atoms whose tuples go through the exact arithmetic
     for (int i = tid; i < N; i += MFX_SWG) {
       if (!(s_amin[i] <= cut)) continue;
-      const int q0 = atomicAdd(&s_cnt[0], E);
-      for (int e = 0; e < E; ++e)
-        if (q0 + e < MFX_SLIST) s_list[q0 + e] = e * N + i;
+      const int q0 = atomicAdd(&s_cnt[0], 1);
+      if (q0 < MFX_SATOMS) s_list[q0] = i;
     }
     __syncthreads();
-    const int nl = s_cnt[0];
-    auto exact_tuple = [&](int i, int e) {   // column sums of the atom with the two columns of the tuple, then the tuple
-      const int ce = 1 + e;
-      double a11 = 0.0, Y1 = 0.0, a1c = 0.0, a1e = 0.0;
-      for (int m = 0; m < M; ++m) {
-        const double d = elem(m, i);
-        a11 += d * d;
-        Y1 += s_y[m] * d;
-        a1c += d * xx[(size_t)m * NX];
-        a1e += d * xx[(size_t)m * NX + ce];
+    const int na = s_cnt[0];
+    if (na <= MFX_SATOMS) {
+      // The usual case, a handful of atoms: the workgroup stages their rotated columns in LDS (the table look-ups of all
+      // of them in flight together), 32 lanes per atom take one of the reference's sequential column sums each (|d|^2,
+      // d.y, d.x_e: every sum still runs over the rows in order), then one lane per tuple solves the triple and sums its
+      // explicit residual from the staged column.  (A lane walking 2 x M table rows per tuple on its own is a chain of
+      // L2 round trips: three quarters of this class's time.)
+      for (int q = tid; q < na * M; q += MFX_SWG) { const int c = q / M, m = q - c * M; s_col[q] = elem(m, s_list[c]); }
+      __syncthreads();
+      for (int q = tid; q < na * 32; q += MFX_SWG) {
+        const int c = q >> 5, sl = q & 31;
+        const double* d = s_col + (size_t)c * M;
+        double acc = 0.0;
+        if (sl == 0) { for (int m = 0; m < M; ++m) acc += d[m] * d[m]; }
+        else if (sl == 1) { for (int m = 0; m < M; ++m) acc += s_y[m] * d[m]; }
+        else if (sl - 2 < NX) { const int e = sl - 2; for (int m = 0; m < M; ++m) acc += d[m] * xx[(size_t)m * NX + e]; }
+        s_sum[q] = acc;
       }
-      double w[3], r;
-      auto explicit_res = [&](const double* ww) {
-        double rr = 0.0;
-        for (int m = 0; m < M; ++m) {
-          const double t = (ww[0] * elem(m, i) + ww[1] * xx[(size_t)m * NX] + ww[2] * xx[(size_t)m * NX + ce] - s_y[m]);
-          rr += t * t;
-        }
-        return rr;
-      };
-      nnls3_cramer(y_sq, a11, a1c, a1e, Gxx[0], Gxx[ce], Gxx[ce * NX + ce], Y1, s_Yx[0], s_Yx[ce], explicit_res, w, r);
-      consider(r, (long)e * N + i, w[0], w[1], w[2]);
-    };
-    if (nl <= MFX_SLIST) {
-      for (int q = tid; q < nl; q += MFX_SWG) exact_tuple(s_list[q] % N, s_list[q] / N);
-    } else {   // (a voxel in which most atoms tie, e.g. no fascicle signal at all: every tuple of the qualifying atoms)
+      __syncthreads();
+      for (int q = tid; q < na * E; q += MFX_SWG) {
+        const int c = q / E, e = q - c * E, ce = 1 + e, i = s_list[c];
+        const double* d = s_col + (size_t)c * M;
+        const double a11 = s_sum[c * 32], Y1 = s_sum[c * 32 + 1], a1c = s_sum[c * 32 + 2], a1e = s_sum[c * 32 + 2 + ce];
+        double w[3], r;
+        auto explicit_res = [&](const double* ww) {
+          double rr = 0.0;
+          for (int m = 0; m < M; ++m) {
+            const double t = (ww[0] * d[m] + ww[1] * xx[(size_t)m * NX] + ww[2] * xx[(size_t)m * NX + ce] - s_y[m]);
+            rr += t * t;
+          }
+          return rr;
+        };
+        nnls3_cramer(y_sq, a11, a1c, a1e, Gxx[0], Gxx[ce], Gxx[ce * NX + ce], Y1, s_Yx[0], s_Yx[ce], explicit_res, w, r);
+        consider(r, (long)e * N + i, w[0], w[1], w[2]);
+      }
+    } else {   // (a voxel in which many atoms tie, e.g. no fascicle signal at all: every tuple of the qualifying atoms, one per lane)
       for (int q = tid; q < N * E; q += MFX_SWG) {
-        const int i = q % N;
-        if (s_amin[i] <= cut) exact_tuple(i, q / N);
+        const int i = q % N, e = q / N, ce = 1 + e;
+        if (!(s_amin[i] <= cut)) continue;
+        double a11 = 0.0, Y1 = 0.0, a1c = 0.0, a1e = 0.0;
+        for (int m = 0; m < M; ++m) {
+          const double d = elem(m, i);
+          a11 += d * d;
+          Y1 += s_y[m] * d;
+          a1c += d * xx[(size_t)m * NX];
+          a1e += d * xx[(size_t)m * NX + ce];
+        }
+        double w[3], r;
+        auto explicit_res = [&](const double* ww) {
+          double rr = 0.0;
+          for (int m = 0; m < M; ++m) {
+            const double t = (ww[0] * elem(m, i) + ww[1] * xx[(size_t)m * NX] + ww[2] * xx[(size_t)m * NX + ce] - s_y[m]);
+            rr += t * t;
+          }
+          return rr;
+        };
+        nnls3_cramer(y_sq, a11, a1c, a1e, Gxx[0], Gxx[ce], Gxx[ce * NX + ce], Y1, s_Yx[0], s_Yx[ce], explicit_res, w, r);
+        consider(r, (long)e * N + i, w[0], w[1], w[2]);
       }
     }
   } else if (K == 1) {

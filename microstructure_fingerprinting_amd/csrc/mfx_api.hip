@@ -607,7 +607,7 @@ struct ExtrasHost {
 
 static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   const int M = a.P.M;
-  const size_t lds = sizeof(double) * (3 * (size_t)M + MFX_NXMAX + 8 + MFX_SWG + 3 * MFX_SWG + (size_t)a.T.N) + sizeof(long) * MFX_SWG +
+  const size_t lds = sizeof(double) * (3 * (size_t)M + MFX_NXMAX + 8 + MFX_SWG + 3 * MFX_SWG + (size_t)a.T.N + MFX_SATOMS * ((size_t)M + 32) + (size_t)M * a.X.NX) + sizeof(long) * MFX_SWG +
                      sizeof(int) * (2 * (size_t)M + MFX_SLIST + 1);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "too many measurements (%d) or atoms (%d) for the one-fascicle kernel", M, a.T.N);
   if (int rc = mfx_prof_begin(st)) return rc;
