@@ -93,19 +93,7 @@ hipError_t mfx_scratch_alloc(void** p, size_t bytes, hipStream_t s) {
   }
   A->used = ++T.arena_clock;
   bytes = ((bytes ? bytes : 8) + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
-  if (A->live == 0) {
-    A->cur = 0; A->off = 0;
-    if (A->blocks.size() > 1) {   // the arena grew during the last call: one block of the total size from now on
-      size_t total = 0;
-      for (size_t b : A->sizes) total += b;
-      if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-      arena_drop(*A);
-      void* nb = nullptr;
-      const size_t want = total + total / 4;
-      if ((e = hipMalloc(&nb, want)) != hipSuccess) return e;
-      A->blocks.push_back(nb); A->sizes.push_back(want);
-    }
-  }
+  if (A->live == 0) { A->cur = 0; A->off = 0; }   // a new call: the same requests land in the same places, nothing grows
   while (A->cur < A->blocks.size() && A->off + bytes > A->sizes[A->cur]) { ++A->cur; A->off = 0; }
   if (A->cur == A->blocks.size()) {   // a new block (hipMalloc synchronises the device; rare: sizes settle after a call or two)
     const size_t last = A->sizes.empty() ? 0 : A->sizes.back();

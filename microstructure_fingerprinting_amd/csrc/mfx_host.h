@@ -91,8 +91,8 @@ struct DevMem {
   template <class T> T* as() const { return (T*)p; }
 };
 // Scratch memory of a call (per-workgroup slabs, short lists, extra columns, Gram / candidate buffers) comes from an ARENA
-// per (host thread, stream): a few device blocks that are only ever grown, handed out by bumping an offset, and taken
-// back when the call's last StreamMem dies.  Calls on one stream execute in order, so the next call may reuse the
+// per (host thread, stream): a few device blocks (a new one whenever a request does not fit: hipMalloc, once), handed out
+// by bumping an offset through them in order, and taken back when the call's last StreamMem dies.  Calls on one stream execute in order, so the next call may reuse the
 // addresses while the previous one is still running; different streams and different host threads have their own arenas.
 // No HIP allocator call in the steady state: on the MI355X boxes of round 2 memory of HIP's DEFAULT stream-ordered pool
 // read back as zeros after being re-mapped (tools/micro/mempool_remap.hip), and hipFreeAsync - also into a
