@@ -309,12 +309,20 @@ __global__ __launch_bounds__(MFX_SWG) void mfx_fit_small_kernel(FitSmallArgs a) 
       }
     }
   }
+  // workgroup minimum of (residual, scan key) with consider()'s rule, as a tree (a serial fold over the 256 thread results
+  // by one thread was 4 us of every voxel); the owner of the winning pair then publishes its weights
   s_res[tid] = bres;
   s_key[tid] = bkey;
-  s_w[3 * tid] = bw[0]; s_w[3 * tid + 1] = bw[1]; s_w[3 * tid + 2] = bw[2];
   __syncthreads();
-  if (tid == 0) {
-    for (int t = 1; t < MFX_SWG; ++t) consider(s_res[t], s_key[t], s_w[3 * t], s_w[3 * t + 1], s_w[3 * t + 2]);
+  for (int o = MFX_SWG / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      const double r1 = s_res[tid], r2 = s_res[tid + o];
+      const long k1 = s_key[tid], k2 = s_key[tid + o];
+      if (r2 < r1 || (r2 == r1 && k1 >= 0 && k2 < k1)) { s_res[tid] = r2; s_key[tid] = k2; }
+    }
+    __syncthreads();
+  }
+  if (bres == s_res[0] && bkey == s_key[0]) {   // (keys of real tuples are unique; several threads in the initial state write the same zeros)
     s_misc[2] = bres; s_misc[3] = bw[0]; s_misc[4] = bw[1]; s_misc[5] = bw[2];
     ((long*)s_misc)[6] = bkey;
   }
