@@ -893,11 +893,13 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   const int M = p->d.M;
   const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   if (V == 0) return MFX_OK;
-  // chunks of up to ~32 MB of signal, the first ones smaller (1/8, 1/4, 1/2 of that) so that the first kernel starts
+  // chunks of up to ~128 MB of signal (MFX_CHUNK_MB; per chunk every voxel class is one launch sequence: with 32 MB chunks
+  // a mixed ROI spent 12 % more time in launch tails), the first ones smaller (1/8, 1/4, 1/2 of that) so that the first kernel starts
   // after a short staging copy; per chunk the voxels are binned by class (K, csf, ear); the direction check runs
   // once per batch on the host (the reference checks per voxel inside interp_PGSE_from_multishell, mf_utils.py:1798-1802)
   HostTrace tr;
-  const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, ((int64_t)32 << 20) / ((int64_t)M * 8)));
+  static const int64_t chunk_mb = [] { const char* e = std::getenv("MFX_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return (int64_t)(v > 0 ? v : 128); }();
+  const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, (chunk_mb << 20) / ((int64_t)M * 8)));
   std::vector<int64_t> cstart;                   // first voxel of every chunk, then V
   for (int64_t v0 = 0, n = std::max<int64_t>(1024, CH / 8); v0 < V; n = std::min<int64_t>(CH, 2 * n)) {
     cstart.push_back(v0);
