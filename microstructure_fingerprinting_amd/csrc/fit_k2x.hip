@@ -142,8 +142,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   double* s_a2x = s_a1x + NW * 16 * MFX_XS;       // [2 buf][16 cols][XS]
   double* s_Yx = s_a2x + 2 * 16 * MFX_XS;         // [XS]
   double* s_Gxx = s_Yx + MFX_XS;                  // [XS][XS]
-  double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [32]
-  double* s_Qx = s_red + 32;                      // [XS]            best support made of extra columns only, per extra tuple
+  double* s_red = s_Gxx + MFX_XS * MFX_XS;        // [24] (per-wave partials 0..NW-1, [16]: np.sum(y**2))
+  double* s_Qx = s_red + 24;                      // [XS]            best support made of extra columns only, per extra tuple
   CandX* s_cand = (CandX*)(s_Qx + MFX_XS);        // [NW][XMAXC / NW] every wave's own short list
   FamX* s_fam = (FamX*)(s_cand + MFX_XMAXC);      // [XFAM]
   double* s_tc = (double*)(s_fam + MFX_XFAM);     // [XS][4] per extra tuple: l_t, 1/r_t, y.x_t', q0_t   + [2]: 1/|f|, y.f/|f|

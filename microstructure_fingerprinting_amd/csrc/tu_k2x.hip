@@ -10,7 +10,7 @@
 static size_t k2x_lds_bytes(int ksteps, bool bracket, int NP, int nw, int nbuf, int ntup, int M, int NX) {
   const size_t MP = (size_t)ksteps * 4;
   size_t dbl = (size_t)nbuf * MP * 16 + MP + 2 * MP + (bracket ? 2 * MP + 2 * MP : 0) + 4 * (size_t)NP + (size_t)nw * 16 * MFX_XS +
-               2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 32 + MFX_XS +        // ... s_Qx
+               2 * 16 * MFX_XS + MFX_XS + MFX_XS * MFX_XS + 24 + MFX_XS +        // ... s_Qx
                (4 * MFX_XS + 2) + (size_t)nw * 16 + 2 * 16 + 2;                    // s_tc, s_rowf, s_colf, s_thr
   dbl += (size_t)M * NX;                                                           // s_xx
   return dbl * 8 + sizeof(CandX) * MFX_XMAXC + sizeof(FamX) * MFX_XFAM + sizeof(ProjC) * ((size_t)nw * 16 + 2 * 16) * ntup +
