@@ -9,8 +9,14 @@ ONE 1e5-voxel ROI over the ranks (BASELINE config 3 as worded); no data-path col
 builds the dictionary tables and broadcasts them once over RCCL.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W [--scaling strong]      # starts the N ranks itself (see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts
+`torch.distributed.run` with N ranks of this same script as a CHILD process, passes their output through and exits with
+their code.  Inside a rank, WORLD_SIZE must equal --gpus and (backend nccl) every rank must own a device, or the rank
+exits non-zero: a line with `n_gpus: N` is never printed by fewer than N devices.
 
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries, measured in the same process over a few
 steps each: the FP64 kernel on the same voxels (`fp64_kernel`), BASELINE configs 4, 1 and 5 (`c4`, `c1`, `c5`), the two-fascicle + CSF class (`k2_csf`), the
@@ -115,19 +121,103 @@ def timed(step, steps, warmup, dev, lib):
     return dt, (float(np.mean(kms)) if kms and min(kms) > 0 else None)
 
 
-def main():
-    a = parse()
+def launch_ranks(a, argv):
+    """`bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD process (the reference's analogue is
+    `mp.Pool(cpu_count)`, mf.py:978-1009) and hand back its exit code.  Nothing in THIS process has touched or will touch
+    the GPU (no torch.cuda call, the library is not loaded): a process that has initialised the GPU must not be replaced or
+    forked, so the decision is taken before anything else runs.  Rank 0 prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this platform
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(a, world, rank):
+    """MFX_BENCH_STUB=1 (tests/test_bench_launcher.py, CPU only): the whole multi-rank skeleton of main() - rendezvous,
+    dictionary broadcast, shard sizes, barriers around the timed region, MAX over ranks, one JSON line from rank 0 - with
+    a step that computes nothing.  The line says so in `metric` and `data`; it is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from microstructure_fingerprinting_amd import dist as mdist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    ms = sch = None
+    if rank == 0:
+        sch, dic, ms = build_model(min(a.atoms, 64))
+    if world > 1:
+        ms, sch = mdist.broadcast_interpolator(ms, sch, src=0)
+    if a.scaling == "strong" and world > 1:
+        lo, hi = mdist.shard_range(a.voxels, rank, world)
+        V, global_V = hi - lo, a.voxels
+    else:
+        V, global_V = a.voxels, world * a.voxels
+    acc = np.zeros(1)
+
+    def step():
+        acc[0] += float(ms.num_subs)      # nothing is fitted
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = max(time.perf_counter() - t0, 1e-9)
+    vpr = [V]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        vpr = [None] * world
+        dist.all_gather_object(vpr, V)
+    if rank == 0:
+        print(json.dumps({"metric": "STUB - no kernel ran (launcher / rendezvous / sharding skeleton only)", "value": 0.0,
+                          "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(elapsed / a.steps * 1e3, 6), "higher_is_better": True,
+                          "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "voxels_per_rank": vpr, "global_voxels": global_V,
+                                     "ranks_in_group": dist.get_world_size() if world > 1 else 1,
+                                     "table_atoms_after_broadcast": int(ms.num_subs)}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(a=None):
+    a = a or parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # the line must never claim more (or fewer) GPUs than ranks took part
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches the ranks "
+                         "itself) or under torch.distributed.run with --nproc-per-node equal to --gpus\n" % (a.gpus, world))
+        sys.exit(2)
+    if os.environ.get("MFX_BENCH_STUB") == "1":
+        return stub_main(a, world, rank)
     import torch
     import torch.distributed as dist
     from microstructure_fingerprinting_amd import _lib as L
     from microstructure_fingerprinting_amd import engine
     from microstructure_fingerprinting_amd import mf_utils as mfu
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("MFX_BENCH_BACKEND", "nccl")     # "gloo" only for rehearsals on a 1-GPU box
     ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.stderr.write("bench.py: %d ranks but only %d visible GPU(s): one process per GPU, no sharing\n" % (world, ndev))
+        sys.exit(3)
     dev_index = (local_rank % ndev) if world > 1 else 0
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
@@ -187,10 +277,19 @@ def main():
     lib.mfx_set_profiling(0)
     L.check(lib.mfx_plan_status(plan.handle(), stream.cuda_stream))
     elapsed = t1 - t0
+    ranks_seen, vox_per_rank, dev_per_rank = 1, [V], [torch.cuda.get_device_name(dev)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the process group really was: ranks, their shard sizes, the device each one ran on (PCI bus id: two ranks
+        # on one card would show the same id)
+        ranks_seen = dist.get_world_size()
+        info = [None] * world
+        dist.all_gather_object(info, (V, "%s #%d %s" % (torch.cuda.get_device_name(dev), dev.index or 0,
+                                                        getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", ""))))
+        vox_per_rank = [i[0] for i in info]
+        dev_per_rank = [i[1] for i in info]
     ms_per_step = elapsed / a.steps * 1e3
     value = global_V * a.steps / elapsed
     handed_back = int(lib.mfx_debug_last_fallback_count())
@@ -257,10 +356,12 @@ def main():
                "config": {"workload": "C2: %d voxels%s, 2 fascicles, %d atoms x %d measurements"
                                       % (a.voxels, "/GPU" if a.scaling == "weak" else " in total", N, M),
                           "voxels_per_gpu": global_V // world, "global_voxels": global_V, "atoms": N, "measurements": M,
+                          "ranks_in_group": ranks_seen, "backend": backend if world > 1 else None,
+                          "voxels_per_rank": vox_per_rank, "device_per_rank": dev_per_rank,
                           "sharding": "voxel shards, no data-path collective; dictionary broadcast once over RCCL"},
                "roofline": roof, "cpu_baseline": cpu}
         res.update(extras)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -423,4 +524,7 @@ def cpu_baseline(sch, ms, d_Y, peaks_h, d_out, V, nsample):
 
 
 if __name__ == "__main__":
-    main()
+    _a = parse()
+    if _a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(_a, sys.argv[1:]))      # before any GPU call in this process
+    main(_a)
