@@ -488,39 +488,53 @@ def cpu_model():
 
 
 def cpu_baseline(sch, ms, d_Y, peaks_h, d_out, V, nsample):
-    """Time the CPU oracle (compiled restatement of the reference algorithm) on a bounded sample of
-    the same voxels, on ALL host cores of this box (one worker per core: the analogue of the reference's
-    mp.Pool(cpu_count), mf.py:980-988) and on one core (parallel=False), and check the GPU result against it."""
+    """Time the CPU oracle (compiled restatement of the reference algorithm) on a bounded sample of the same voxels:
+    one thread (the reference's parallel=False loop, mf.py:1017-1028) and 16 / 32 / 64 / all usable host threads (one worker
+    per core: the analogue of mp.Pool(cpu_count), mf.py:978-1009).  `value` is the BEST of the multi-thread legs - with two
+    hardware threads per core the working set of a voxel (2.5 MB of rotated dictionaries swept 782 times by the reference's
+    Gram loop, mf_utils.py:315-319) falls out of the cores' shared L3 and the all-thread leg can be slower than the
+    one-per-core leg; every leg is listed.  The GPU result is checked against the oracle on the largest sample."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    nthreads = max(1, min(cores, orc.max_threads()))
-    if nsample <= 0:
-        nsample = 40 * nthreads           # ~20 voxels/s/core: about 2 s of wall clock per leg, whatever the box
-    nsample = min(nsample, V)
+    nmax = max(1, min(cores, orc.max_threads()))
     T = {"S": ms.S, "N": ms.num_subs, "G_un": ms.Gms_un, "off": ms.off, "x": ms.x_flat, "Y": ms.Y_flat}
-    Ys = d_Y[:nsample].cpu().numpy()
-    pk = np.ascontiguousarray(peaks_h[:nsample])
-    K = np.full(nsample, 2, dtype=np.int32)
-    z = np.zeros(nsample, dtype=np.uint8)
-    n1 = min(nsample, 48)
-    t0 = time.perf_counter()
-    orc.fit_batch(T, sch, Ys[:n1], K[:n1], z[:n1], z[:n1], pk[:n1], 2, False, False, None, None, 0, nthreads=1)
-    t1 = time.perf_counter()
-    ref = orc.fit_batch(T, sch, Ys, K, z, z, pk, 2, False, False, None, None, 0, nthreads=nthreads)
-    t2 = time.perf_counter()
-    got = d_out[:nsample].cpu().numpy()
+    legs_nt = sorted({n for n in (16, 32, 64, nmax) if n <= nmax} | {nmax})
+    per = nsample // max(len(legs_nt), 1) if nsample > 0 else 0
+    nbig = min(V, max((per if per > 0 else 30 * n) for n in legs_nt))
+    Ys = d_Y[:nbig].cpu().numpy()
+    pk = np.ascontiguousarray(peaks_h[:nbig])
+    K = np.full(nbig, 2, dtype=np.int32)
+    z = np.zeros(nbig, dtype=np.uint8)
+
+    def run(n, nt):
+        t0 = time.perf_counter()
+        r = orc.fit_batch(T, sch, Ys[:n], K[:n], z[:n], z[:n], pk[:n], 2, False, False, None, None, 0, nthreads=nt)
+        return n / (time.perf_counter() - t0), r
+
+    n1 = min(nbig, 48)
+    single, _ = run(n1, 1)
+    legs, ref, nref = [], None, 0
+    for nt in legs_nt:
+        n = min(nbig, per if per > 0 else 30 * nt)     # ~20 voxels/s/thread: 1.5-3 s of wall clock per leg, whatever the box
+        rate, r = run(n, nt)
+        legs.append({"threads": nt, "voxels": n, "value": round(rate, 2), "per_thread": round(rate / nt, 3),
+                     "efficiency_vs_single_thread": round(rate / (nt * single), 3)})
+        if n >= nref:
+            ref, nref = r, n
+    best = max(legs, key=lambda l: l["value"])
+    got = d_out[:nref].cpu().numpy()
     ids_equal = bool(np.array_equal(got[:, 3:5], ref[:, 3:5]))
     relerr = float(np.max(np.abs(got[:, :3] - ref[:, :3]) / np.maximum(np.abs(ref[:, :3]), 1e-300)))
-    return {"value": round(nsample / (t2 - t1), 2), "unit": "voxels/s", "cores": nthreads, "cores_total": os.cpu_count(),
+    return {"value": best["value"], "unit": "voxels/s", "cores": best["threads"], "cores_total": os.cpu_count(),
             "cpu_model": cpu_model(), "kind": "port",
-            "sample": "%d voxels of the same workload, %d OpenMP threads = one per usable host core (mp.Pool analogue); "
-                      "single-thread leg: %d voxels" % (nsample, nthreads, n1),
-            "single_thread_value": round(n1 / (t1 - t0), 3),
-            "parity_on_sample": {"atom_ids_equal": ids_equal, "max_rel_err_weights": relerr}}
+            "sample": "%d voxels of the same workload on %d OpenMP threads (best of the legs below; one worker per thread: "
+                      "mp.Pool analogue); single-thread leg: %d voxels" % (best["voxels"], best["threads"], n1),
+            "single_thread_value": round(single, 3), "legs": legs,
+            "parity_on_sample": {"voxels": nref, "atom_ids_equal": ids_equal, "max_rel_err_weights": relerr}}
 
 
 if __name__ == "__main__":

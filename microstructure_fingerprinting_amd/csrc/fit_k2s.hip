@@ -40,7 +40,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFX_S_DC
 #define MFX_S_DC 1e-5       // bound on |c~ - c|
+#endif
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
 #define MFX_S_BOUND 0x40000000   // ring entry flag (in .j): .score is an upper bound (interval bound, single atom), not S(c~)
 #define MFX_S_GUARD 0.25    // run-time guard: an exactly evaluated pair whose screening score was off by more than this
@@ -722,6 +724,9 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     };
     auto scan_tile = [&](const f32x16& acc, int ct) { scan_pre(ct); scan_main(acc, ct); };
 
+#ifdef MFX_EXP_NOTAIL   // timing experiment (wrong results): what the shared last row tile costs
+    if (tail) continue;
+#endif
     if (tail) {
 #ifdef MFX_STAMPS_RND
       if (a.stamps && tid == 0 && round < 4) a.stamps[(size_t)blockIdx.x * 16 + 2 * round + 1] = __builtin_amdgcn_s_memtime();
@@ -868,6 +873,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       if (round == 0) MFX_STAMP(4);
       thr = __longlong_as_double((long long)s_thr[0]);
       int b0 = 0;   // buffer of chunk c
+#ifdef MFX_EXP_NOGEN   // timing experiment (wrong results): rounds after the first find their chunk images ready-made
+      const bool exp_gen = round == 0;
+#else
+      constexpr bool exp_gen = true;
+#endif
       for (int c = 0; c <= ntiles; ++c) {
 #ifdef MFX_STAMPS_HS   // diagnostic builds: start of 16 periods as seen by wave 0 (tools/dev_stamps_hs.py; default: periods 10..25 of round 1)
 #ifndef MFX_HS_ROUND
@@ -880,15 +890,15 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
         if (grp == 0) {
           if (c < ntiles) {
             if (rt_valid) { mfma_chunk(b0); scan_pre(c); }
-            if (c + 2 < ntiles) gen_store(c + 2, b2);
+            if (exp_gen && c + 2 < ntiles) gen_store(c + 2, b2);
             if (rt_valid) scan_main(acc, c);
-            if (c + 3 < ntiles) gen_load(c + 3);
+            if (exp_gen && c + 3 < ntiles) gen_load(c + 3);
           }
         } else {
           if (c >= 1 && rt_valid) scan_pre(c - 1);
-          if (c + 1 < ntiles) gen_store(c + 1, b1);
+          if (exp_gen && c + 1 < ntiles) gen_store(c + 1, b1);
           if (c >= 1 && rt_valid) scan_main(acc, c - 1);
-          if (c + 2 < ntiles) gen_load(c + 2);
+          if (exp_gen && c + 2 < ntiles) gen_load(c + 2);
           if (c < ntiles && rt_valid) mfma_chunk(b0);
         }
         // LDS-only workgroup barrier: __syncthreads() would also wait for the table loads just issued (vmcnt)

@@ -401,26 +401,26 @@ class MFModelFit():
             print("Microstructure Fingerprinting fit object constructed; maps: %s" % ", ".join(names))
 
     def write_nifti(self, output_basename, affine=None):
-        """Export every map as ``<basename>_<param>.nii[.gz]`` (ref:1177-1229); returns the file names."""
-        if affine is None:
-            affine = self.affine
-        if affine is None:
+        """One NIfTI file per parameter map, ``<stem>_<param><ext>``; returns the file names (reference mf.py:1177-1229).
+        ``output_basename`` may end in .nii.gz (kept), .nii or nothing (both give .nii); any other extension is refused."""
+        xfm = self.affine if affine is None else affine
+        if xfm is None:
             raise ValueError("Argument affine must be explicitely passed  because no affine transform matrix was "
                              "found during model fitting. Expecting NumPy array with shape (4, 4).")
-        niigz = '.nii.gz'
-        if len(output_basename) > len(niigz) and output_basename[-len(niigz):] == niigz:
-            path, fname = os.path.split(output_basename[:-len(niigz)])
-            ext = niigz
-        else:
-            path, tail = os.path.split(output_basename)
-            fname, ext = os.path.splitext(tail)
-            if ext not in ['', '.nii']:
-                raise ValueError("Unknown NIfTI extension %s in output %s" % (ext, output_basename))
-            ext = '.nii'
-        base = os.path.join(path, fname)
-        fnames = []
-        for p in self.param_names:
-            fn = '%s_%s%s' % (base, p, ext)
-            nifti.save(getattr(self, p), affine, fn)
-            fnames.append(fn)
-        return fnames
+        stem, ext = _nifti_stem(output_basename)
+        written = []
+        for name in self.param_names:
+            target = "%s_%s%s" % (stem, name, ext)
+            nifti.save(getattr(self, name), xfm, target)
+            written.append(target)
+        return written
+
+
+def _nifti_stem(output_basename):
+    """('dir/name', '.nii' | '.nii.gz') of an output name for MFModelFit.write_nifti."""
+    if output_basename.endswith('.nii.gz') and len(output_basename) > len('.nii.gz'):
+        return output_basename[:-len('.nii.gz')], '.nii.gz'
+    stem, ext = os.path.splitext(output_basename)
+    if ext and ext != '.nii':
+        raise ValueError("Unknown NIfTI extension %s in output %s" % (ext, output_basename))
+    return stem, '.nii'

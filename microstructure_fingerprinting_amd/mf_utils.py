@@ -395,47 +395,65 @@ def import_PGSE_scheme(scheme):
     return sch
 
 
-def get_PGSE_scheme_from_bval_bvec_dense(sch_mat_dense, bvals, bvecs, Gtol=1e-3):
-    """Scheme matrix from b-values [s/mm^2] / b-vectors, snapping G onto the dense scheme's shells
-    within ``Gtol`` [T/m] (ref:2197-2300)."""
-    ref = import_PGSE_scheme(sch_mat_dense)
-    if isinstance(bvals, str):
-        bvals = np.loadtxt(bvals)
-    if isinstance(bvecs, str):
-        bvecs = np.atleast_2d(np.loadtxt(bvecs))
-    bvals = np.asarray(bvals, dtype=np.float64) * 1e6          # s/mm^2 -> s/m^2
-    if np.ndim(bvecs) != 2:
-        raise ValueError("bvecs array should have 2 dimensions, detected %d." % np.ndim(bvecs))
-    if bvecs.shape[0] != bvals.size and bvecs.shape[1] != bvals.size:
-        raise ValueError("Number of b-vectors does not match number of b-values (%d)" % bvals.size)
-    if not np.all(np.all(ref[0, 4:6] == ref[:, 4:6], axis=1)):
-        raise ValueError('Detected different pairs of (Delta, delta) values in reference scheme matrix '
-                         '(note that zeros count as values), which is currently not supported.')
-    sch = np.zeros((bvals.size, 7))
+def _as_text_table(x):
+    """A b-value / b-vector argument: a path to a whitespace-separated text file, or array-like."""
+    return np.loadtxt(x) if isinstance(x, str) else np.asarray(x)
+
+
+def _gradient_rows(bvecs, n):
+    """b-vectors as an [n x 3] array of unit rows (zero rows stay zero).  Accepts 3 x n (FSL) and n x 3; a 3 x 3 input is
+    read as 3 x n like the reference does (its test on shape[0] comes first, ref:2253-2259)."""
     if bvecs.shape[0] == 3:
-        sch[:, :3] = bvecs.transpose()
+        g = np.array(bvecs.T, dtype=np.float64)
     elif bvecs.shape[1] == 3:
-        sch[:, :3] = bvecs
+        g = np.array(bvecs, dtype=np.float64)
     else:
         raise ValueError("Vectors in bvecs should be 3-dimensional. However, detected no dimension with size 3.")
-    gn = np.sqrt(np.sum(sch[:, :3] ** 2, axis=1))
-    sch[gn > 0, :3] = sch[gn > 0, :3] / gn[gn > 0][:, np.newaxis]
-    Dl, dl, TE = ref[0, 4], ref[0, 5], ref[0, 6]
-    G = np.sqrt(bvals / (Dl - dl / 3)) / (get_gyromagnetic_ratio('H') * dl)
-    Geff = np.zeros(bvals.shape[0])
-    mapped = 0
-    for Gt in np.unique(ref[:, 3]):
-        hit = np.where(np.abs(Gt - G) < Gtol)[0]
-        mapped += hit.size
-        Geff[hit] = Gt
-    if mapped != G.size:
+    length = np.sqrt(np.sum(g ** 2, axis=1))
+    nz = length > 0
+    g[nz] = g[nz] / length[nz][:, np.newaxis]
+    return g
+
+
+def _snap_to_shells(G, shells, Gtol):
+    """Each gradient intensity in G replaced by the dense scheme's shell value within Gtol of it; the number of
+    (value, shell) matches must equal G.size - a value near no shell, or near two, is the reference's mapping error.
+    Where two shells match the larger one would win (the reference assigns shell after shell in ascending order)."""
+    near = np.abs(G[:, np.newaxis] - shells[np.newaxis, :]) < Gtol         # [n, S]
+    n_matches = int(np.count_nonzero(near))
+    last_match = near.shape[1] - 1 - np.argmax(near[:, ::-1], axis=1)
+    return np.where(near.any(axis=1), shells[last_match], 0.0), n_matches
+
+
+def get_PGSE_scheme_from_bval_bvec_dense(sch_mat_dense, bvals, bvecs, Gtol=1e-3):
+    """Subject protocol [gx gy gz G Delta delta TE] from b-values [s/mm^2] and b-vectors, for a dictionary simulated on the
+    dense multi-shell scheme ``sch_mat_dense``: timing (Delta, delta, TE) is the dense scheme's - which must be a single
+    one - and every b-value is turned into a gradient intensity and snapped onto the dense scheme's shell within ``Gtol``
+    [T/m] of it (reference mf_utils.py:2197-2300; same ValueErrors)."""
+    dense = import_PGSE_scheme(sch_mat_dense)
+    b_si = np.asarray(_as_text_table(bvals), dtype=np.float64).ravel() * 1e6          # s/mm^2 -> s/m^2
+    vec = _as_text_table(bvecs)
+    if isinstance(bvecs, str):
+        vec = np.atleast_2d(vec)
+    n = b_si.size
+    if np.ndim(vec) != 2:
+        raise ValueError("bvecs array should have 2 dimensions, detected %d." % np.ndim(vec))
+    if n not in vec.shape:
+        raise ValueError("Number of b-vectors does not match number of b-values (%d)" % n)
+    timing = dense[:, 4:6]
+    if not np.all(timing == timing[0]):
+        raise ValueError('Detected different pairs of (Delta, delta) values in reference scheme matrix '
+                         '(note that zeros count as values), which is currently not supported.')
+    Delta, delta, TE = dense[0, 4:7]
+    G = np.sqrt(b_si / (Delta - delta / 3)) / (get_gyromagnetic_ratio('H') * delta)     # b = (gamma G delta)^2 (Delta - delta/3)
+    G_shell, n_matches = _snap_to_shells(G, np.unique(dense[:, 3]), Gtol)
+    g = _gradient_rows(vec, n)
+    if n_matches != n:
         raise ValueError('Mismatch between reference scheme matrix and bvals.  Could only map %d/%d b-values '
                          '(equivalently, gradient intensities G) from the specified bvals to the b-values '
                          'contained in the reference scheme matrix. You may want to change the tolerance on '
-                         'gradient intensity G (currently %g T/m).' % (mapped, G.size, Gtol))
-    sch[:, 3] = Geff
-    sch[:, 4:7] = np.array([Dl, dl, TE])
-    return sch
+                         'gradient intensity G (currently %g T/m).' % (n_matches, n, Gtol))
+    return np.column_stack([g, G_shell, np.full(n, Delta), np.full(n, delta), np.full(n, TE)])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -481,25 +499,28 @@ def DT_vec_to_2Darray(DT_vec, order):
 
 
 def DT_vec_to_peaks(DT_vec, order, mask=None):
-    """Unit principal eigenvector of each tensor, zero vector for an all-zero tensor (ref:960-1019)."""
-    DT_vec = np.asarray(DT_vec)
-    was_1d = DT_vec.ndim == 1
-    if DT_vec.ndim < 2:
-        DT_vec = np.atleast_2d(DT_vec)
-    if DT_vec.shape[-1] != 6:
-        raise ValueError('DT_vec should have size 6 along last dimension. Detected %d.' % (DT_vec.shape[-1],))
-    if mask is None:
-        mask = np.ones(DT_vec.shape[:-1], dtype=bool)
-    mask = np.asarray(mask)
-    if mask.ndim != DT_vec.ndim - 1:
+    """Principal direction of every tensor in a (..., 6) array: the unit eigenvector of the largest eigenvalue, a zero
+    vector where that eigenvalue is zero (an all-zero tensor) and outside ``mask`` (reference mf_utils.py:960-1019).
+    A single 6-vector gives a single 3-vector."""
+    tensors = np.asarray(DT_vec)
+    single = tensors.ndim == 1
+    if single:
+        tensors = tensors[np.newaxis, :]
+    if tensors.shape[-1] != 6:
+        raise ValueError('DT_vec should have size 6 along last dimension. Detected %d.' % (tensors.shape[-1],))
+    grid = tensors.shape[:-1]
+    inside = np.ones(grid, dtype=bool) if mask is None else np.asarray(mask)
+    if inside.ndim != len(grid):
         raise ValueError('mask should have %d dimension(s) since DT_vec has %d, detected %d instead.'
-                         % (DT_vec.ndim - 1, DT_vec.ndim, mask.ndim))
-    sel = mask > 0
-    lam, vec = np.linalg.eigh(DT_vec_to_2Darray(DT_vec[sel, :], order))    # ascending eigenvalues
-    keep = (np.abs(lam[..., -1]) > 0)[:, np.newaxis]
-    peaks = np.zeros(mask.shape + (3,))
-    peaks[sel] = vec[..., -1] * keep
-    return np.squeeze(peaks) if was_1d else peaks
+                         % (len(grid), len(grid) + 1, inside.ndim))
+    inside = inside > 0
+    peaks = np.zeros(grid + (3,))
+    if np.any(inside):
+        evals, evecs = np.linalg.eigh(DT_vec_to_2Darray(tensors[inside], order))      # eigenvalues ascending
+        principal = evecs[:, :, 2]
+        principal[np.abs(evals[:, 2]) == 0] = 0.0                # eigh hands back the identity for a zero tensor
+        peaks[inside] = principal
+    return peaks[0] if single and peaks.shape[0] == 1 else (np.squeeze(peaks) if single else peaks)
 
 
 def peaks_to_DT_vec(peaks, order, lam_par=2e-3, lam_perp=0.1e-3):

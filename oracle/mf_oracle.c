@@ -94,6 +94,28 @@ static double np_pairwise_sumsq(const double* a, long n) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* Per-thread scratch for the Gram arrays of solve2 / solve3 (4.9 MB per config-2 voxel): grown once per thread and kept
+ * across the voxels of a batch, released when the thread leaves orc_fit_batch / orc_solve_exhaustive.  A calloc + free
+ * per voxel is an mmap + munmap of fresh pages per voxel; with one worker per host core they serialise in the kernel
+ * (the reference's process pool, mf.py:978-1009, lets Numba allocate per call too, but its workers do not share an
+ * address space).  What needs zeros is cleared explicitly below. */
+static __thread double* tl_scratch = NULL;
+static __thread size_t tl_scratch_cap = 0;
+static double* scratch_get(size_t n) {
+  if (n > tl_scratch_cap) {
+    free(tl_scratch);
+    tl_scratch = (double*)malloc(n * sizeof(double));
+    tl_scratch_cap = tl_scratch ? n : 0;
+  }
+  return tl_scratch;
+}
+static void scratch_release(void) {
+  free(tl_scratch);
+  tl_scratch = NULL;
+  tl_scratch_cap = 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* solve_exhaustive_posweights_1: mfu:225-278 */
 static void solve1(const double* A, long lda, int M, long N, const double* y, double* w_out, long* sub,
                    double* min_obj_out) {
@@ -124,11 +146,12 @@ static void solve1(const double* A, long lda, int M, long N, const double* y, do
 /* solve_exhaustive_posweights_2: mfu:288-392 */
 static int solve2(const double* A, long lda, int M, long N1, long N2, const double* y, double* w_out, long* sub,
                   double* min_obj_out) {
-  double* A11 = (double*)calloc(N1, sizeof(double));
-  double* A22 = (double*)calloc(N2, sizeof(double));
-  double* A12 = (double*)calloc((size_t)N1 * N2, sizeof(double));
-  double* Ady = (double*)calloc(N1 + N2, sizeof(double));
-  if (!A11 || !A22 || !A12 || !Ady) return ORC_ERR_ARG;
+  double* A11 = scratch_get((size_t)N1 + N2 + (size_t)N1 * N2 + N1 + N2);
+  if (!A11) return ORC_ERR_ARG;
+  double* A22 = A11 + N1;
+  double* Ady = A22 + N2;
+  double* A12 = Ady + N1 + N2;                                   /* every entry is assigned below */
+  memset(A11, 0, sizeof(double) * (size_t)(2 * (N1 + N2)));      /* A11, A22, Ady: np.zeros, mfu:300-304 */
   for (long i1 = 0; i1 < N1; i1++) /* mfu:307-310 */
     for (int k = 0; k < M; k++) A11[i1] += A[k * lda + i1] * A[k * lda + i1];
   for (long i2 = 0; i2 < N2; i2++) /* mfu:311-314 */
@@ -164,7 +187,6 @@ static int solve2(const double* A, long lda, int M, long N1, long N2, const doub
   sub[0] = s0;
   sub[1] = s1;
   *min_obj_out = min_obj;
-  free(A11); free(A22); free(A12); free(Ady);
   return ORC_OK;
 }
 
@@ -174,14 +196,16 @@ static int solve3(const double* A, long lda, int M, long N1, long N2, long N3, c
   const long s_ind[3] = {0, N1, N1 + N2};
   const double eps = 2.2204e-16; /* mfu:480 */
   const double tol = 100 * eps;
-  double* A11 = (double*)calloc(N1, sizeof(double));
-  double* A22 = (double*)calloc(N2, sizeof(double));
-  double* A33 = (double*)calloc(N3, sizeof(double));
-  double* A12 = (double*)calloc((size_t)N1 * N2, sizeof(double));
-  double* A13 = (double*)calloc((size_t)N1 * N3, sizeof(double));
-  double* A23 = (double*)calloc((size_t)N2 * N3, sizeof(double));
-  double* Ady = (double*)calloc(N1 + N2 + N3, sizeof(double));
-  if (!A11 || !A22 || !A33 || !A12 || !A13 || !A23 || !Ady) return ORC_ERR_ARG;
+  const size_t nsum = (size_t)N1 + N2 + N3;
+  double* A11 = scratch_get(2 * nsum + (size_t)N1 * N2 + (size_t)N1 * N3 + (size_t)N2 * N3);
+  if (!A11) return ORC_ERR_ARG;
+  double* A22 = A11 + N1;
+  double* A33 = A22 + N2;
+  double* Ady = A33 + N3;
+  double* A12 = Ady + nsum;                                      /* the three cross-Grams are assigned entry by entry */
+  double* A13 = A12 + (size_t)N1 * N2;
+  double* A23 = A13 + (size_t)N1 * N3;
+  memset(A11, 0, sizeof(double) * 2 * nsum);                     /* norms and Ady: np.zeros, mfu:488-497 */
 #define COL(k, c) A[(k) * lda + (c)]
   for (long i = 0; i < N1; i++)
     for (int k = 0; k < M; k++) A11[i] += COL(k, s_ind[0] + i) * COL(k, s_ind[0] + i);
@@ -255,7 +279,6 @@ static int solve3(const double* A, long lda, int M, long N1, long N2, long N3, c
 #undef COL
   for (int i = 0; i < 3; i++) { w_out[i] = wb[i]; sub[i] = sb[i]; }
   *min_obj_out = min_obj;
-  free(A11); free(A22); free(A33); free(A12); free(A13); free(A23); free(Ady);
   return ORC_OK;
 }
 
@@ -517,8 +540,8 @@ int orc_nnls(const double* A, int M, int n, const double* b, double* x, double* 
 }
 
 /* solve_exhaustive_posweights: mfu:115-214 (dispatch; validation lives in the Python wrapper) */
-int orc_solve_exhaustive(const double* A, long lda, int M, const long* sizes, int Kp, const double* y, double* w,
-                         long* sub, long* tot, double* min_obj, double* y_rec) {
+static int solve_exhaustive(const double* A, long lda, int M, const long* sizes, int Kp, const double* y, double* w,
+                            long* sub, long* tot, double* min_obj, double* y_rec) {
   int rc = ORC_OK;
   if (Kp == 1) solve1(A, lda, M, sizes[0], y, w, sub, min_obj);
   else if (Kp == 2) rc = solve2(A, lda, M, sizes[0], sizes[1], y, w, sub, min_obj);
@@ -534,6 +557,12 @@ int orc_solve_exhaustive(const double* A, long lda, int M, const long* sizes, in
     y_rec[i] = (Kp == 1) ? w[0] * A[i * lda + tot[0]] : t;
   }
   return ORC_OK;
+}
+int orc_solve_exhaustive(const double* A, long lda, int M, const long* sizes, int Kp, const double* y, double* w,
+                         long* sub, long* tot, double* min_obj, double* y_rec) {
+  const int rc = solve_exhaustive(A, lda, M, sizes, Kp, y, w, sub, tot, min_obj, y_rec);
+  scratch_release();   /* a single problem: nothing to keep the Gram arrays for */
+  return rc;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -664,7 +693,7 @@ static int fit_voxel(int S, int N, const double* G_un, const int* off, const dou
   (void)dicsize;
   double w[4], SoS;
   long sub[4], tot[4];
-  int rc = orc_solve_exhaustive(D, maxdic, M, sizes, Kp, y, w, sub, tot, &SoS, y_rec);
+  int rc = solve_exhaustive(D, maxdic, M, sizes, Kp, y, w, sub, tot, &SoS, y_rec);
   if (rc) return rc;
   double M0 = 0.0;
   for (int k = 0; k < Kp; k++) M0 += w[k]; /* np.sum of <=4 values: plain loop */
@@ -724,6 +753,7 @@ int orc_fit_batch(int S, int N, const double* G_un, const int* off, const double
       if (rc) err = rc;
     }
     free(D); free(tmp); free(yrec);
+    scratch_release();   /* this thread's Gram arrays, kept across its voxels */
   }
   return err;
 }

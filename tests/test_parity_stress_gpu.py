@@ -652,6 +652,57 @@ def test_three_dictionaries_fast_path_vs_oracle():
         assert np.allclose(yrec, yrecr, rtol=1e-9, atol=1e-9)
 
 
+def test_three_fascicles_oracle_refereed_at_n400():
+    """Config 5's class where the triple screen is under pressure: three fascicles, 400 atoms x 300
+    measurements (6.4e7 triples per voxel, ~100 s per voxel for the oracle's solve_exhaustive_posweights_3: one voxel per
+    host thread), through mfx_fit_batch with maxfasc = 3.  Voxels: generic mixtures at SNR 30, signals made of two atoms
+    and of one atom only (every triple sharing the active atoms nearly ties: the reference's first hit in its
+    i3 -> i1 -> i2 order must win), two peaks 3 degrees apart, identical peaks, noise-free data.  Atom indices must equal
+    the oracle's, weights and objective to 1e-9."""
+    from concurrent.futures import ThreadPoolExecutor
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    N = int(os.environ.get("MFX_K3_REFEREE_N", "400"))
+    rng = np.random.default_rng(77)
+    sch = synth.make_scheme(rng, 1, [1000, 2000, 3000, 4000], [75, 75, 75, 74])
+    M = sch.shape[0]
+    assert M == 300
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    T = _tables(ms)
+    kinds = ["generic"] * 5 + ["two_atoms", "two_atoms", "one_atom", "cross3", "cross3", "identical", "noise_free"]
+    V = len(kinds)
+    p = [synth.unit_vectors(rng, V) for _ in range(3)]
+    nu = rng.dirichlet(np.ones(3) * 2, V)
+    for v, kd in enumerate(kinds):
+        if kd == "two_atoms": nu[v] = [0.55, 0.45, 0.0] if v % 2 else [0.0, 0.3, 0.7]
+        if kd == "one_atom": nu[v] = [0.0, 1.0, 0.0]
+        if kd == "cross3": p[1][v] = _second_peak(rng, p[0][v:v + 1], 3.0)[0]
+        if kd == "identical": p[2][v] = p[0][v]
+    peaks = np.concatenate(p, axis=1)
+    atoms = rng.integers(0, N, (V, 3))
+    Y = np.zeros((V, M))
+    for k in range(3):
+        Y += 500.0 * nu[:, k:k + 1] * _rotate_cols(plan, peaks[:, 3 * k:3 * k + 3], atoms[:, k])
+    noisy = np.array([kd != "noise_free" for kd in kinds])
+    Y[noisy] += rng.normal(0, 500.0 / 30.0, (int(noisy.sum()), M))
+    got = engine.fit_batch(plan, Y, np.full(V, 3), None, None, peaks, 3, False, False)
+    sizes = np.array([N, N, N])
+
+    def referee(v):
+        A = np.ascontiguousarray(np.concatenate([orc.interp(sch, peaks[v, 3 * k:3 * k + 3], T) for k in range(3)], axis=1))
+        return orc.solve_exhaustive_posweights(A, Y[v], sizes)
+    with ThreadPoolExecutor(max_workers=min(V, NTHREADS)) as ex:     # the C oracle runs outside the GIL
+        refs = list(ex.map(referee, range(V)))
+    for v, (w, sub, tot, mo, yrec) in enumerate(refs):
+        assert np.array_equal(got[v, 4:7], sub.astype(float)), (v, kinds[v], got[v], sub, w)
+        ws = w.sum()
+        assert np.isclose(got[v, 0], ws, rtol=1e-9) and np.allclose(got[v, 1:4], w / ws if abs(ws) > 0 else w, rtol=1e-9, atol=1e-12)
+        assert np.isclose(got[v, -2], mo / M, rtol=1e-9, atol=1e-12 * float(Y[v] @ Y[v]) / M), (v, kinds[v], got[v, -2] * M, mo)
+
+
 def test_c5_full_size_properties():
     """BASELINE config 5 at its full size - three fascicles, 1500 atoms x 300 measurements, 3.4e9 triples per voxel -
     through mfx_fit_batch_dev (two voxels in flight).  The oracle would need hours per voxel here, so the checks are
