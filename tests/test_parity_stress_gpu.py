@@ -122,6 +122,55 @@ def test_k2_stress_regimes_vs_oracle_full_size():
     assert nfb < 0.05 * V
 
 
+def test_k2_worst_operand_family_as_dictionary_vs_oracle():
+    """The operand family with the largest measured split-FP16 product error (tools/micro/split_mfma_error.hip, family 1:
+    smooth positive decays over the measurement index at table scale, near-collinear pairs; worst |c~ - c| 1.05e-6 at
+    K = 208) fed through the WHOLE two-fascicle fit as a dictionary, against the oracle.  The atoms
+    are isotropic - a_n(m) = A_n exp(-3 p_n s(m) / S) with s(m) the shell of measurement m, 67 shells x 3 directions -
+    so that every rotation returns exactly these vectors and both rotated dictionaries are the family itself: 782 atoms x
+    200 measurements, the screening kernel's config-2 instantiation.  Mixtures of two atoms at SNR 30 / 100, noise-free,
+    one atom only.  Indices must equal the oracle's (pairs (i, j) and (j, i) tie exactly: first hit), weights to 1e-9;
+    the run-time guard must stay silent."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2024)
+    S, N = 67, 782                                    # a b0 shell (2 rows) + 66 shells x 3 directions = 200 measurements
+    sch = synth.make_scheme(rng, 2, list(np.linspace(200.0, 10000.0, S - 1)), [3] * (S - 1))
+    az = rng.uniform(0, 2 * np.pi, sch.shape[0])
+    uz = np.tile([0.15, 0.5, 0.85], S)[1:]            # |g.z| of the three directions of a shell: well separated knots
+    sch[2:, 0], sch[2:, 1], sch[2:, 2] = (np.sqrt(1 - uz ** 2) * np.cos(az))[2:], (np.sqrt(1 - uz ** 2) * np.sin(az))[2:], uz[2:]
+    M = sch.shape[0]
+    assert M == 200
+    shell = np.concatenate([[0, 0], np.repeat(np.arange(1, S), 3)])
+    amp, rate = 0.3 + 0.7 * rng.random(N), rng.random(N)
+    dic = amp[None, :] * np.exp(-3.0 * rate[None, :] * shell[:, None] / S)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    V = int(os.environ.get("MFX_WORST_FAMILY_V", "384"))
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    atoms = rng.integers(0, N, (V, 2))
+    nu = rng.dirichlet(np.ones(2), V)
+    nu[V // 2: V // 2 + V // 8] = [1.0, 0.0]
+    Y = 500.0 * (nu[:, :1] * dic[:, atoms[:, 0]].T + nu[:, 1:] * dic[:, atoms[:, 1]].T)
+    q = V // 4
+    Y[:q] += rng.normal(0, 500.0 / 30.0, (q, M))
+    Y[q:2 * q] += rng.normal(0, 500.0 / 100.0, (q, M))
+    Y[3 * q:] += rng.normal(0, 500.0 / 30.0, (V - 3 * q, M))
+    dev = torch.device("cuda", 0)
+    lib = L.lib()
+    lib.mfx_debug_set_k2_screen(1)
+    got = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2).cpu().numpy()
+    nfb, ngd = lib.mfx_debug_last_fallback_count(), lib.mfx_debug_last_guard_count()
+    z = np.zeros(V, bool)
+    ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0, nthreads=NTHREADS)
+    _assert_rows(got, ref, 2, "worst operand family", rtol=1e-9)
+    assert ngd == 0, "screening-error guard tripped on %d voxels" % ngd
+    print("worst operand family: %d voxels identical to the oracle, handed back %d, guard %d" % (V, nfb, ngd))
+
+
 def _ukbb_model():
     d = np.load(os.path.join(G, "real_ukbb.npz"))
     model = {k: d[k] for k in d.files if k != "sch_subj"}
