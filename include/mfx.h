@@ -186,7 +186,10 @@ int mfx_debug_last_guard_count(void);
  * two-fascicle + CSF/EAR kernel 2 short-listed pairs, 3 family items (one-atom / no-atom supports and ambiguous slots
  * evaluated exactly), 4 voxels of the [N, N, 1] screening pipeline handed to the FP64 kernel of the class (ring overflow,
  * an atom inside the span of the CSF column, list overflow, bound check), 5 of them by the bound check (a listed pair
- * whose exact score exceeds its screening bound by more than the margin), summed over the batch; which = 0..7. */
+ * whose exact score exceeds its screening bound by more than the margin), summed over the batch; and the screening
+ * kernels' population audit (every two-fascicle voxel compares the split-FP16 cross product of ONE pseudo-random atom pair
+ * with its FP64 value, listed or not): 8 audited pairs whose error exceeds a quarter of the screening margin, 9 the largest
+ * error in units of 1e-11 (cosine units), 10 audited pairs; which = 0..11. */
 int mfx_debug_last_counter(int which);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);

@@ -68,6 +68,9 @@ struct FitK2Args {
   double* xl_mrg;       // [gridDim.x] the voxel's screening margin (score units)
   int xl_cap;
   int vox_base;         // voxel (or vox_list entry) of block 0
+  // screening kernels: population audit of the split-FP16 cross product (k2s_shared.h) - [0] audited pairs with
+  // |c~ - c| > MFX_S_DC / 4, [1] the largest |c~ - c| in units of 1e-11, [2] audited pairs; null: no audit
+  int* audit;
 };
 
 #ifdef MFX_STAMPS
@@ -319,15 +322,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
       for (int r = 0; r < 4; ++r) z1r[r] = s_Y1[rtc * 16 + lg + 4 * r];
       // two-positive-weights case of one accumulator entry; both MFMA operands are normalised when they
       // are generated: c = cos(atom i, atom j), z = d.y/|d|
-      auto scan_one = [&](double c, int r, int j, double z2) {
+      // (returns true for a pair with two positive weights whose 1 - c^2 is too small to be ranked as a fraction: see ill_pairs)
+      auto scan_one = [&](double c, int r, int j, double z2) -> bool {
         const double e1 = fma(-c, z2, z1r[r]);
         const double e2 = fma(-c, z1r[r], z2);
         const double den = fma(-c, c, 1.0);
         const double num = fma(z2, e2, z1r[r] * e1);
-        const bool better = (e1 > 0.0) & (e2 > 0.0) & (den > MFX_DET_REL) & (num * bq[r] > bp[r] * den);
+        const bool pos = (e1 > 0.0) & (e2 > 0.0);
+        const bool better = pos & (den > MFX_DET_REL) & (num * bq[r] > bp[r] * den);
         bp[r] = better ? num : bp[r];
         bq[r] = better ? den : bq[r];
         bj[r] = better ? j : bj[r];
+        return pos & !(den > MFX_DET_REL);
+      };
+      // Nearly collinear atom pairs (1 - c^2 <= MFX_DET_REL) whose two-atom solution has two positive weights cannot be
+      // ranked - the score's error grows like 1/(1 - c^2) - but the reference does solve them (mf_utils.py:348-356: no test on
+      // Det), and down to 1 - c^2 ~ 1e-12 its answer is well defined.  They go to the short list unranked (always
+      // evaluated exactly; with them their slot row, see phase 3).  Real dictionaries have none (HCP: 1 - c^2 >= 8e-4); a
+      // dictionary of two-parameter decays has dozens per voxel, and a voxel whose list overflows takes the exhaustive pass.
+      auto ill_pairs = [&](const d4& acc, int j, double z2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double c = acc[r];
+          const bool ill = (fma(-c, z2, z1r[r]) > 0.0) && (fma(-c, z1r[r], z2) > 0.0) && !(fma(-c, c, 1.0) > MFX_DET_REL);
+          const int i = rtc * 16 + lg + 4 * r;
+          if (ill && rt_valid && i < N && j < N) {
+            const int slot = atomicAdd(&s_cnt[0], 1);
+            if (slot < MFX_MAXC) { s_cand[slot].score = 1e300; s_cand[slot].i = i; s_cand[slot].j = j; }
+          }
+        }
       };
       constexpr int NEL = (MP + 15) / 16;                                  // D2 elements per thread per chunk
       constexpr int GS = (KSTEPS - 5) / NEL > 0 ? (KSTEPS - 5) / NEL : 1;  // k-steps between two element loads
@@ -383,13 +406,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
           const int j0 = ch * 32 + lc, j1 = j0 + 16;
           if constexpr (T0) {
             const double z20 = (j0 < NP) ? s_Y2[min(j0, NP - 1)] : 0.0;
+            bool ill = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scan_one(acc0[r], r, j0, z20);
+            for (int r = 0; r < 4; ++r) ill |= scan_one(acc0[r], r, j0, z20);
+            if (__any(ill)) ill_pairs(acc0, j0, z20);
           }
           if constexpr (T1) {
             const double z21 = (j1 < NP) ? s_Y2[min(j1, NP - 1)] : 0.0;
+            bool ill = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scan_one(acc1[r], r, j1, z21);
+            for (int r = 0; r < 4; ++r) ill |= scan_one(acc1[r], r, j1, z21);
+            if (__any(ill)) ill_pairs(acc1, j1, z21);
           }
         };
         if (mode == 1) body(std::integral_constant<int, 1>{});
@@ -416,8 +443,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2_kernel(Fi
         const double pd = A11r[r] * A22;
         const double Det = fma(-A12, A12, pd);
         const double num = fma(Y2, d2, Y1r[r] * d1);
-        // (numerically) collinear atom pairs carry no two-atom information: rank them by their
-        // best single atom; MFX_DET_REL bounds the score error of every pair ranked as a fraction
+        // nearly collinear atom pairs cannot be ranked as a fraction (MFX_DET_REL bounds the score error of every pair
+        // that is); with two positive weights they go to the short list unranked, as in the FAST variant (rare: a branch)
+        if ((d1 > 0.0) && (d2 > 0.0) && !(Det > MFX_DET_REL * pd) && colok && rowok[r]) {
+          const int slot = atomicAdd(&s_cnt[0], 1);
+          if (slot < MFX_MAXC) { s_cand[slot].score = 1e300; s_cand[slot].i = rtc * 16 + lg + 4 * r; s_cand[slot].j = j; }
+        }
         const bool both = (d1 > 0.0) & (d2 > 0.0) & (Det > MFX_DET_REL * pd);
         double p = both ? num : 0.0;   // single-active cases: the two best single atoms, see phase 1
         const double q = both ? Det : 1.0;

@@ -8,8 +8,8 @@
 // So the Gram is computed here from operands split into two FP16 halves (mfx_split16),
 //        a = hi + lo (+ r),  |r| <= 2^-21 |a|,      c~ = hi.hi + hi.lo + lo.hi
 // on v_mfma_f32_32x32x16_f16 (3 instructions per 32x32x16 block, 32x the FP64 MFMA rate), with unit-norm
-// columns so that c~ is the cosine of the pair up to |c~ - c| <= DC (DC = 1e-5 is >10x the measured
-// maximum, bound: 3 * 2^-21 truncation + FP32 accumulation of 13 MFMA steps over sum|a_i b_i| <= 1).
+// columns so that c~ is the cosine of the pair up to |c~ - c| <= DC (MFX_S_DC below: 1.5e-5, a bound under one measured
+// assumption about the matrix pipe's FP32 summation; 13x the largest error measured).
 // For a pair whose optimum has two positive weights the score S = |y|^2 - residual obeys dS/dc = -2 w1 w2
 // with w1 w2 <= |y|^2 / 2 (c >= 0), so |S(c~) - S(c)| <= DC |y|^2 =: m.  Every pair with S(c~) >= thr is
 // appended to a ring in LDS, thr = (largest S(c~) seen) - 2m, which can only drop pairs that are not the
@@ -40,8 +40,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Bound on |c~ - c| (cosine units).  A statement under ONE measured assumption:
+//   operands: every rotated entry is one FP32 fma of FP32 table values (<= 3 roundings): |da| <= 2.4e-7 |a|  -> 4.8e-7
+//   split:    a = hi + lo + r, |r| <= 2^-21 |a|; dropped lo.lo + r.b + a.r <= 2^-19 |a b| per term           -> 1.9e-6
+//   matrix pipe: ASSUMPTION - one v_mfma_f32_32x32x16_f16 returns its 17 addends' sum (16 exact products + accumulator)
+//             within kappa 2^-24 (|c| + sum |a_k b_k|), kappa <= 5.1: the largest value tools/micro/mfma_sum_model.hip
+//             finds over 15 adversarial operand families, 1.6e7 cases (profiles/r03_micro_mfma_sum_model.txt: 5.02;
+//             2.0 on positive dictionary-like operands; the pipe does NOT round once - 12-46 % of the results differ
+//             from the correctly rounded sum); 39 dependent instructions, every partial sum <= sum |a_i b_i| <= |a||b|
+//             (Cauchy-Schwarz), the hi.lo / lo.hi addends 2^-10 of it:  39 x 5.1 x 2^-24 x 1.002                -> 1.19e-5
+//   total 1.43e-5 <= MFX_S_DC.  (Measured: worst 1.14e-6 over 46 M adversarial pairs, tools/micro/split_mfma_error.hip;
+//   and every voxel audits one pseudo-random pair of its own, k2s_shared.h.)
 #ifndef MFX_S_DC
-#define MFX_S_DC 1e-5       // bound on |c~ - c|
+#define MFX_S_DC 1.5e-5
 #endif
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
 #define MFX_S_BOUND 0x40000000   // ring entry flag (in .j): .score is an upper bound (interval bound, single atom), not S(c~)
@@ -150,6 +161,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   double bs1 = 0.0;   // best single atom of D1 among the row tiles this wave has generated
   int bn1 = 0;
   const int nrounds = (ntiles + NW - 1) / NW;
+  // the voxel's audited pair (k2s_shared.h): its row tile and column chunk; the shared last row tile is not audited
+  const int aud_key = (!XC && a.audit) ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
   for (int round = 0; round < nrounds; ++round) {
     // A last round with ONE row tile left (N = 782: 25 = 3*8 + 1) is shared by all waves: each keeps the same
     // A tile and takes every 8th column tile, generating its B operand straight into registers (no LDS image,
@@ -276,6 +289,16 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       ++dbg_calls;
 #endif
       MFX_SCAN_T(0);
+      if constexpr (!XC) {
+        if (((rt << 8) | ct) == aud_key) {   // once per voxel, one wave: park the raw accumulator value of the audited pair (k2s_shared.h)
+          const unsigned h = k2s_audit_hash(vox);
+          const int ga = (h >> 16) & 15;
+          float v = acc[0];
+#pragma unroll
+          for (int g = 1; g < 16; ++g) v = (ga == g) ? acc[g] : v;
+          if (lane == (int)((h >> 20) & 63)) ((float*)(s_red + 30))[0] = v;
+        }
+      }
       const int j = ct * 32 + lr;
       // row i = rt*32 + (g&3) + 8(g>>2) + 4 lh, column j = ct*32 + lr
       thr = fmax(thr, __longlong_as_double((long long)sc_thr));

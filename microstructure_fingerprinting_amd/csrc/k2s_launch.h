@@ -10,15 +10,16 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
   const size_t lds = mfx_k2s_lds_bytes(KS, a.T.N, BR, NB);
   auto kern = mfx_fit_k2s_kernel<KS, BR, NB>;
   HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  StreamMem fbm(st);   // [0] hand-back count, [1] guard count, [2..3] unused, [4..] voxel list
-  HIPCHK(fbm.alloc(sizeof(int) * ((size_t)nvox + 4)));
+  StreamMem fbm(st);   // [0] hand-back count, [1] guard count, [2..4] audit, [8..] voxel list
+  HIPCHK(fbm.alloc(sizeof(int) * ((size_t)nvox + 8)));
   int* fb = fbm.as<int>();
-  HIPCHK(hipMemsetAsync(fb, 0, 4 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(fb, 0, 8 * sizeof(int), st));
   if (int rc = mfx_prof_begin(st)) return rc;
   FitK2Args aa = a;
   aa.stamps = T.stamps;
   aa.fb_count = fb;
-  aa.fb_list = fb + 4;
+  aa.fb_list = fb + 8;
+  aa.audit = fb + 2;   // [2] audited pairs beyond DC/4, [3] largest error (1e-11), [4] audited pairs
   aa.scap = T.k2s_cap ? T.k2s_cap : MFX_S_CAP;
   hipLaunchKernelGGL(kern, dim3(nvox), dim3(512), lds, st, aa);
   HIPCHK(hipGetLastError());
@@ -27,10 +28,11 @@ static int launch_k2s_t(const FitK2Args& a, int nvox, hipStream_t st) {
   // FP64 kernel straight from the device-side list: no host read, the call stays asynchronous.  The launch covers
   // nvox blocks; all but the first *fb exit at once.
   FitK2Args ab = a;
-  ab.vox_list = fb + 4;
+  ab.vox_list = fb + 8;
   ab.list_count = fb;
   if (int rc = mfx_launch_k2_f64(ab, nvox, st, false)) return rc;
-  return mfx_fb_accumulate(fb, 2, st);
+  if (int rc = mfx_fb_accumulate(fb, 2, st)) return rc;
+  return mfx_fb_accumulate_audit(fb + 2, st);
 }
 
 #define MFX_K2S_TU(KS_, NAME_)                                                            \

@@ -94,6 +94,22 @@ struct K2sVoxel {
   double etol;     // |e(c~) - e(c)| <= etol
 };
 
+// Population audit of the screening product.  The run-time guard of the exact stage sees only pairs that were short-listed;
+// a pair that was NOT listed because its c~ was off by more than the margin would go unnoticed.  So every voxel also
+// audits ONE pseudo-random pair of its N^2 (a hash of the voxel index picks row tile, column chunk, accumulator register
+// and lane): the wave that screens that accumulator tile parks the raw accumulator value in LDS, the exact stage sums the
+// pair's Gram scalars in FP64 from the FP64 table and compares the two cosines.  Counted per launch (FitK2Args::audit): a
+// 1e5-voxel launch audits 1e5 pairs of real operands of that very run, whatever was listed.
+__device__ __forceinline__ unsigned k2s_audit_hash(int vox) {
+  unsigned h = (unsigned)vox * 2654435761u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  return h;
+}
+// (row tile << 8) | column chunk of the audited pair, or -1: row tiles of the regular rounds only (ntiles_reg of them)
+__device__ __forceinline__ int k2s_audit_key(unsigned h, int ntiles_reg, int ntiles) {
+  return ntiles_reg > 0 ? (int)(((h & 0xffu) % (unsigned)ntiles_reg) << 8) | (int)(((h >> 8) & 0xffu) % (unsigned)ntiles) : -1;
+}
+
 // ring append (rare path)
 template <class LDS>
 __device__ __forceinline__ void k2s_push(const LDS& L, int scap, double S, int i, int j) {
@@ -151,7 +167,7 @@ __device__ __forceinline__ K2sVoxel k2s_prologue(const FitK2Args& a, const K2sLd
       s_t0f[idx] = (float)ts;
     }
   }
-  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; }
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_thr[0] = 0ull; s_thr[1] = 0ull; ((float*)(s_red + 30))[0] = __int_as_float(0x7fc00000); }   // (audit slot: nothing parked yet)
   if constexpr (XC) {
     for (int m = tid; m < MP; m += WG) s_xf[m] = (m < M) ? (float)a.xc[m] : 0.0f;
     if (tid < 2) ((unsigned long long*)s_red)[24 + tid] = 0ull;   // max |d|^2/|d'|^2 of each dictionary (bits of a non-negative double)
@@ -577,6 +593,40 @@ __device__ __forceinline__ void k2s_finish(const FitK2Args& a, const K2sLds<KS, 
     __syncthreads();
     const int neval = s_cnt[2];
     MFX_STAMP(9);
+    // one WAVE sums the five Gram scalars of the pair (i, j) in the reference's order (mf_utils.py:307-325): the 64 lanes fetch
+    // the 2 x M table entries side by side (all loads of the pair in flight at once), then five lanes run the five sequential
+    // sums from LDS - lane 0: a11 = sum d1*d1, 1: a22 = sum d2*d2, 2: a12 = sum d1*d2, 3: y1 = sum y*d1, 4: y2 = sum y*d2
+    auto wave_sums = [&](int i, int j, double& a11, double& a22, double& a12, double& y1, double& y2) {
+#pragma unroll
+      for (int mb = 0; mb < (MP + 63) / 64; ++mb) {
+        const int m = mb * 64 + lane;
+        if (m < M) {
+          s_stage[m] = elem(0, m, i);
+          s_stage[MP + m] = elem(1, m, j);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const double* pa = (lane == 1) ? s_stage + MP : (lane >= 3 ? s_y : s_stage);
+      const double* pb = (lane == 0 || lane == 3) ? s_stage : s_stage + MP;
+      double acc = 0.0;
+      if (lane < 5) {
+        // blocks of 8 rows: sixteen 16-byte LDS reads in flight, then the 8 dependent multiply-adds in row order
+        // (a read per term leaves its ~100-cycle round trip exposed 200 times: 21 k cycles per candidate)
+        int m = 0;
+        for (; m + 8 <= M; m += 8) {
+          double2 va[4], vb[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { va[q] = *(const double2*)(pa + m + 2 * q); vb[q] = *(const double2*)(pb + m + 2 * q); }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { acc += va[q].x * vb[q].x; acc += va[q].y * vb[q].y; }
+        }
+        for (; m < M; ++m) acc += pa[m] * pb[m];
+      }
+      a11 = mfx_readlane_f64(acc, 0); a22 = mfx_readlane_f64(acc, 1); a12 = mfx_readlane_f64(acc, 2);
+      y1 = mfx_readlane_f64(acc, 3); y2 = mfx_readlane_f64(acc, 4);
+      __builtin_amdgcn_wave_barrier();
+    };
     if (neval <= 24) {
       // few candidates (the usual case): one WAVE per candidate.  A thread-per-candidate loop is bound by the
       // latency of its 2 x 200 dependent-address table loads (51 k cycles whatever the count); here the 64 lanes
@@ -584,36 +634,9 @@ __device__ __forceinline__ void k2s_finish(const FitK2Args& a, const K2sLds<KS, 
       for (int e = wave; e < neval; e += NW) {
         const int cix = s_evl[e];
         const int i = s_cand[cix].i, jf = s_cand[cix].j, j = jf & ~MFX_S_BOUND;
-#pragma unroll
-        for (int mb = 0; mb < (MP + 63) / 64; ++mb) {   // all table loads of the pair in flight at once
-          const int m = mb * 64 + lane;
-          if (m < M) {
-            s_stage[m] = elem(0, m, i);
-            s_stage[MP + m] = elem(1, m, j);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double a11, a22, a12, y1, y2;
+        wave_sums(i, j, a11, a22, a12, y1, y2);
         if (e == 0) MFX_STAMP(15);
-        // lane 0: a11 = sum d1*d1, 1: a22 = sum d2*d2, 2: a12 = sum d1*d2, 3: y1 = sum y*d1, 4: y2 = sum y*d2
-        const double* pa = (lane == 1) ? s_stage + MP : (lane >= 3 ? s_y : s_stage);
-        const double* pb = (lane == 0 || lane == 3) ? s_stage : s_stage + MP;
-        double acc = 0.0;
-        if (lane < 5) {
-          // blocks of 8 rows: sixteen 16-byte LDS reads in flight, then the 8 dependent multiply-adds in row order
-          // (a read per term leaves its ~100-cycle round trip exposed 200 times: 21 k cycles per candidate)
-          int m = 0;
-          for (; m + 8 <= M; m += 8) {
-            double2 va[4], vb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { va[q] = *(const double2*)(pa + m + 2 * q); vb[q] = *(const double2*)(pb + m + 2 * q); }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { acc += va[q].x * vb[q].x; acc += va[q].y * vb[q].y; }
-          }
-          for (; m < M; ++m) acc += pa[m] * pb[m];
-        }
-        const double a11 = mfx_readlane_f64(acc, 0), a22 = mfx_readlane_f64(acc, 1), a12 = mfx_readlane_f64(acc, 2),
-                     y1 = mfx_readlane_f64(acc, 3), y2 = mfx_readlane_f64(acc, 4);
         double r, u0, u1;
         nnls2_exact(y_sq, a11, a12, a22, y1, y2, u0, u1, r);
         const long ix = (long)i * N + j;
@@ -641,6 +664,29 @@ __device__ __forceinline__ void k2s_finish(const FitK2Args& a, const K2sLds<KS, 
         ++dbg_eval;
         if (!(jf & MFX_S_BOUND) && u0 > 0.0 && u1 > 0.0) dbg_err = fmax(dbg_err, fabs((y_sq - r) - s_cand[cix].score) / y_sq);
 #endif
+      }
+    }
+    // population audit (see k2s_audit_hash): the next wave in turn compares the parked accumulator value of this voxel's
+    // audited pair with the cosine from FP64 sums over the FP64 table
+    if constexpr (!XC) {
+      const float accv = ((const float*)(s_red + 30))[0];
+      if (a.audit && accv == accv && wave == (neval <= 24 ? neval % NW : 0)) {
+        const unsigned h = k2s_audit_hash(vox);
+        const int ntl = NP >> 5;
+        const int key = k2s_audit_key(h, (ntl % NW == 1 && ntl > 1) ? ntl - 1 : ntl, ntl);
+        const int ga = (h >> 16) & 15, la = (h >> 20) & 63;
+        const int i = (key >> 8) * 32 + (ga & 3) + 8 * (ga >> 2) + 4 * (la >> 5), j = (key & 0xff) * 32 + (la & 31);
+        const double n12 = (double)s_cs[min(i, NP - 1)] * (double)s_cs[NP + min(j, NP - 1)];
+        if (i < N && j < N && n12 > 0.0) {   // (wave-uniform)
+          double a11, a22, a12, y1, y2;
+          wave_sums(i, j, a11, a22, a12, y1, y2);
+          const double err = fabs((double)accv / n12 - a12 / (sqrt(a11) * sqrt(a22)));
+          if (lane == 0) {
+            atomicAdd(a.audit + 2, 1);
+            atomicMax(a.audit + 1, (int)fmin(err * 1e11, 2.0e9));
+            if (err > 0.25 * MFX_S_DC) atomicAdd(a.audit, 1);
+          }
+        }
       }
     }
 #ifdef MFX_STAMPS

@@ -141,37 +141,48 @@ int mfx_prof_end(hipStream_t st) {
 __global__ void mfx_fb_add_kernel(const int* __restrict__ cnt, int n, int* __restrict__ tot) {   // tot: already offset
   if (threadIdx.x < n) atomicAdd(&tot[threadIdx.x], cnt[threadIdx.x]);
 }
+// audit counters of a screening launch (k2s_shared.h): [0] pairs beyond DC/4 and [2] audited pairs add up, [1] is a maximum
+__global__ void mfx_fb_audit_kernel(const int* __restrict__ cnt, int* __restrict__ tot) {
+  if (threadIdx.x == 0) { atomicAdd(&tot[0], cnt[0]); atomicMax(&tot[1], cnt[1]); atomicAdd(&tot[2], cnt[2]); }
+}
 static int fb_setup() {
   MfxThread& T = mfx_thread();
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (T.fb_dev && T.fb_device == dev) return MFX_OK;
   if (T.fb_dev) { (void)hipFree(T.fb_dev); T.fb_dev = nullptr; }
-  HIPCHK(hipMalloc((void**)&T.fb_dev, 8 * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&T.fb_dev, MFX_NCOUNTERS * sizeof(int)));
   T.fb_device = dev;
   if (!T.fb_host) {
-    HIPCHK(hipHostMalloc((void**)&T.fb_host, 8 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&T.fb_host, MFX_NCOUNTERS * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&T.fb_event, hipEventDisableTiming));
   }
   return MFX_OK;
 }
 int mfx_fb_begin(hipStream_t st) {
   if (int rc = fb_setup()) return rc;
-  HIPCHK(hipMemsetAsync(mfx_thread().fb_dev, 0, 8 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(mfx_thread().fb_dev, 0, MFX_NCOUNTERS * sizeof(int), st));
   return MFX_OK;
 }
 int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st, int offset) {
   MfxThread& T = mfx_thread();
   if (!T.fb_dev) return MFX_OK;   // (a launcher used outside mfx_fit_batch*: nothing to report to)
-  if (offset < 0 || offset + n > 8) return fail(MFX_ERR_ARG, "counter range");
+  if (offset < 0 || offset + n > 8) return fail(MFX_ERR_ARG, "counter range");   // ([8..10]: mfx_fb_accumulate_audit)
   hipLaunchKernelGGL(mfx_fb_add_kernel, dim3(1), dim3(64), 0, st, d_counters, n, T.fb_dev + offset);
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+int mfx_fb_accumulate_audit(const int* d_audit, hipStream_t st) {
+  MfxThread& T = mfx_thread();
+  if (!T.fb_dev) return MFX_OK;
+  hipLaunchKernelGGL(mfx_fb_audit_kernel, dim3(1), dim3(64), 0, st, d_audit, T.fb_dev + 8);
   HIPCHK(hipGetLastError());
   return MFX_OK;
 }
 int mfx_fb_end(hipStream_t st) {
   MfxThread& T = mfx_thread();
   if (!T.fb_dev) return MFX_OK;
-  HIPCHK(hipMemcpyAsync(T.fb_host, T.fb_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(T.fb_host, T.fb_dev, MFX_NCOUNTERS * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(T.fb_event, st));
   T.fb_pending = true;
   return MFX_OK;
@@ -201,7 +212,7 @@ extern "C" double mfx_last_kernel_ms(void) {
 }
 extern "C" int mfx_debug_last_fallback_count(void) { return fb_read(0); }
 extern "C" int mfx_debug_last_guard_count(void) { return fb_read(1); }
-extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < 8) ? fb_read(which) : -1; }
+extern "C" int mfx_debug_last_counter(int which) { return (which >= 0 && which < MFX_NCOUNTERS) ? fb_read(which) : -1; }
 extern "C" void mfx_debug_set_k2_screen(int enabled) { mfx_thread().k2_screen = enabled ? 1 : 0; }
 extern "C" void mfx_debug_set_k2_wide(int mode) { mfx_thread().k2_wide = mode == 1 ? 1 : (mode == 0 ? 0 : 2); }
 extern "C" void mfx_debug_set_k2x_screen(int on) { mfx_thread().k2x_screen = on ? 1 : 0; }

@@ -16,6 +16,8 @@
 #include "fit_k2.hip"
 #include "fit_k2x.hip"
 
+#define MFX_NCOUNTERS 12   // per-call counters (mfx_debug_last_counter): [0..7] hand-backs of the kernel families, [8..10] screening audit
+
 struct MfxThread {
   std::string err;
   // timing hook (mfx_set_profiling / mfx_last_kernel_ms)
@@ -35,8 +37,8 @@ struct MfxThread {
   int k2_wide = -1;        // MFX_K2_WIDE: 1 forces the wide screening kernel (fit_k2w.hip) wherever it applies, 0 never uses it
   // hand-back counters of the last mfx_fit_batch* call: summed on the device over its launches, copied to pinned memory
   // behind the kernels and read only when somebody asks (mfx_debug_last_*_count): the _dev entry points never synchronise
-  int* fb_dev = nullptr;           // device [8]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
-  int* fb_host = nullptr;          // pinned [8]
+  int* fb_dev = nullptr;           // device [MFX_NCOUNTERS]: [0] voxels handed back to an exact kernel, [1] of them by the screening-error guard
+  int* fb_host = nullptr;          // pinned [MFX_NCOUNTERS]
   int fb_device = -1;              // device fb_dev lives on
   hipEvent_t fb_event = nullptr;
   bool fb_pending = false;
@@ -120,6 +122,7 @@ int mfx_prof_end(hipStream_t st);
 // pinned memory, all in stream order behind the work on `st` (no host synchronisation)
 int mfx_fb_begin(hipStream_t st);
 int mfx_fb_accumulate(const int* d_counters, int n, hipStream_t st, int offset = 0);
+int mfx_fb_accumulate_audit(const int* d_audit, hipStream_t st);   // [0] beyond DC/4 (+), [1] largest error (max), [2] audited pairs (+) -> counters 8..10
 int mfx_fb_end(hipStream_t st);
 
 // ---- kernel launchers, one translation unit each

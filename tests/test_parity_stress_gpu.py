@@ -110,6 +110,7 @@ def test_k2_stress_regimes_vs_oracle_full_size():
     out = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2)
     got = out.cpu().numpy()
     nfb, ngd = lib.mfx_debug_last_fallback_count(), lib.mfx_debug_last_guard_count()
+    aud_over, aud_max, aud_n = lib.mfx_debug_last_counter(8), lib.mfx_debug_last_counter(9) * 1e-11, lib.mfx_debug_last_counter(10)
     z = np.zeros(V, bool)
     ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0, nthreads=NTHREADS)
     names = np.array(names)
@@ -120,6 +121,9 @@ def test_k2_stress_regimes_vs_oracle_full_size():
     print("stress regimes: %d voxels, ids exact, max rel err %.2e, handed back %d (guard %d)"
           % (V, float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-300) * (np.abs(ref) > 1e-6))), nfb, ngd))
     assert nfb < 0.05 * V
+    # population audit: (nearly) every voxel compared one pseudo-random pair's split-FP16 cosine with its FP64 value
+    print("screen audit: %d pairs, max |c~ - c| %.2e, beyond a quarter of the margin: %d" % (aud_n, aud_max, aud_over))
+    assert aud_n >= 0.9 * (V - nfb) and aud_over == 0 and 0.0 < aud_max < 2.5e-6
 
 
 def test_k2_worst_operand_family_as_dictionary_vs_oracle():
@@ -164,11 +168,14 @@ def test_k2_worst_operand_family_as_dictionary_vs_oracle():
     lib.mfx_debug_set_k2_screen(1)
     got = engine.fit_batch_dev(plan, torch.from_numpy(Y).to(dev), torch.from_numpy(peaks).to(dev), 2).cpu().numpy()
     nfb, ngd = lib.mfx_debug_last_fallback_count(), lib.mfx_debug_last_guard_count()
+    aud_over, aud_max, aud_n = lib.mfx_debug_last_counter(8), lib.mfx_debug_last_counter(9) * 1e-11, lib.mfx_debug_last_counter(10)
     z = np.zeros(V, bool)
     ref = orc.fit_batch(_tables(ms), sch, Y, np.full(V, 2), z, z, peaks, 2, False, False, None, None, 0, nthreads=NTHREADS)
     _assert_rows(got, ref, 2, "worst operand family", rtol=1e-9)
     assert ngd == 0, "screening-error guard tripped on %d voxels" % ngd
-    print("worst operand family: %d voxels identical to the oracle, handed back %d, guard %d" % (V, nfb, ngd))
+    print("worst operand family: %d voxels identical to the oracle, handed back %d, guard %d; audit: %d pairs, max |c~ - c| %.2e"
+          % (V, nfb, ngd, aud_n, aud_max))
+    assert aud_over == 0 and aud_max < 2.5e-6
 
 
 def _ukbb_model():

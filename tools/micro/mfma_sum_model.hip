@@ -144,6 +144,19 @@ int main() {
   for (auto& v : B) v = H(2047.0 / 1024.0);
   for (size_t q = 0; q < ncase; ++q) C[q] = std::ldexp((float)(16777215 - (int)(q % 1000)), -18 + (int)(q % 9));
   note(run("22-bit products (all mantissa bits set), 24-bit c"));
+  // 9-12. truncation probes: full-mantissa factors (2047/1024 and neighbours) with the exponents of the 16 products spread
+  // over W binades, positive: after alignment to the largest addend every smaller one has low bits to lose
+  for (int W : {2, 4, 8, 12, 24}) {
+    for (size_t q = 0; q < A.size(); ++q) A[q] = H(std::ldexp((2047.0 - (double)(rng() % 4)) / 1024.0, -(int)(rng() % (unsigned)W)));
+    for (auto& v : B) v = H((2047.0 - (double)(rng() % 4)) / 1024.0);
+    for (size_t q = 0; q < ncase; ++q) C[q] = (q % 3 == 0) ? 0.0f : std::ldexp((float)(16777215 - (int)(rng() % 64)), -22 - (int)(rng() % (unsigned)W));
+    char nm[96];
+    snprintf(nm, sizeof nm, "full-mantissa positive addends spread over %d binades", W);
+    note(run(nm));
+  }
+  // 13. the same, random signs
+  for (size_t q = 0; q < A.size(); ++q) A[q] = H((rng() & 1 ? -1.0 : 1.0) * std::ldexp((2047.0 - (double)(rng() % 4)) / 1024.0, -(int)(rng() % 8u)));
+  note(run("full-mantissa addends over 8 binades, random signs"));
   printf("worst over the families: kappa_max %.3f  kappa_sum %.4f   (|result - exact| <= kappa_sum * 2^-24 * (|c| + sum|a_k b_k|))\n", worst_max, worst_sum);
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
   return 0;
