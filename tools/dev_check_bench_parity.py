@@ -47,3 +47,4 @@ if bad.size:
                         np.ascontiguousarray(peaks_h[sel]), 2, False, False, None, None, 0, nthreads=8)
     for q, v in enumerate(sel):
         print(v, "\n  screen", a[v], "\n  fp64  ", b[v], "\n  oracle", ref[q])
+sys.exit(1 if bad.size else 0)
