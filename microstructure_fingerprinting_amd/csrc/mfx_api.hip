@@ -20,6 +20,7 @@
 #include "rotate.hip"
 #include "solve_generic.hip"
 #include "solve_k3.hip"
+#include "fit_k3.hip"
 #include "mc_average.hip"
 #include "cleanup.hip"
 #include "mfx_device.h"
@@ -625,6 +626,9 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
 static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list,
                              int nvox, int K, const ExtrasHost& X, int maxfasc, int csf_on, int ear_on, double* d_params,
                              hipStream_t st);
+static bool k3b_applies(int K, int NX, int N, long ntuples);
+static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list, int nvox,
+                          int maxfasc, int csf_on, int ear_on, double* d_params, hipStream_t st);
 
 // h_list: host copy of d_list (null with d_list == null: the identity)
 static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
@@ -655,7 +659,13 @@ static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_p
     a.params = d_params; a.num_params = num_params; a.maxfasc = maxfasc; a.csf_on = csf_on; a.ear_on = ear_on;
     return mfx_launch_k2x(a, nvox, st);
   }
-  if (K == 3) return fit_class_generic(p, d_Y, d_peaks, peaks_ld, h_list, nvox, K, X, maxfasc, csf_on, ear_on, d_params, st);
+  if (K == 3) {
+    MfxThread& T = mfx_thread();
+    if (T.k3_batch < 0) { const char* e = getenv("MFX_K3_BATCH"); T.k3_batch = (e && e[0] == '0') ? 0 : 1; }
+    if (T.k3_batch && k3b_applies(K, X.d.NX, p->t->d.N, (long)p->t->d.N * p->t->d.N * p->t->d.N))
+      return fit_k3_batched(p, d_Y, d_peaks, peaks_ld, h_list, nvox, maxfasc, csf_on, ear_on, d_params, st);
+    return fit_class_generic(p, d_Y, d_peaks, peaks_ld, h_list, nvox, K, X, maxfasc, csf_on, ear_on, d_params, st);
+  }
   return fail(MFX_ERR_UNSUPPORTED, "voxel class (K=%d, csf=%d, ear=%d) not implemented", K, has_csf, has_ear);
 }
 
@@ -690,6 +700,87 @@ static int launch_solver(SolveArgs a, const K3Bufs* k3, hipStream_t st) {
   }
   HIPCHK(hipGetLastError());
   return MFX_OK;
+}
+
+// Three fascicles without extra columns (BASELINE config 5) in batches of voxels: fit_k3.hip.  Everything is enqueued on `st`.
+#define MFX_K3B_BATCH 8
+static bool k3b_applies(int K, int NX, int N, long ntuples) { return K == 3 && NX == 0 && N >= 32 && ntuples >= (1L << 18); }
+static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list, int nvox,
+                          int maxfasc, int csf_on, int ear_on, double* d_params, hipStream_t st) {
+  const int M = p->d.M, N = p->t->d.N, LD = 3 * N;
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
+  const int BT = std::min(nvox, MFX_K3B_BATCH);
+  const size_t nn = (size_t)N * N;
+  StreamMem dA(st), dG(st), dcol(st), dst3(st), dsm(st), dcs(st), dct(st), dpart(st), dout(st), dvox(st);
+  HIPCHK(dA.alloc(sizeof(double) * (size_t)BT * M * LD));
+  HIPCHK(dG.alloc(sizeof(double) * (size_t)BT * 3 * nn));
+  HIPCHK(dcol.alloc(sizeof(double) * ((size_t)BT * LD * 2 + (size_t)BT * 2)));
+  HIPCHK(dst3.alloc(sizeof(double2) * (size_t)BT * N));
+  HIPCHK(dsm.alloc(sizeof(unsigned long long) * (size_t)BT * 8 + sizeof(int) * (size_t)BT * 2));
+  const bool k3dbg = getenv("MFX_K3_DEBUG") != nullptr;
+  HIPCHK(dcs.alloc(sizeof(double) * (size_t)BT * MFX_K3B_CAP));
+  HIPCHK(dct.alloc(sizeof(long) * (size_t)BT * MFX_K3B_CAP));
+  HIPCHK(dpart.alloc(sizeof(double) * (size_t)BT * MFX_K3B_FW * 8));
+  HIPCHK(dout.alloc(sizeof(double) * ((size_t)BT * 8 + (size_t)BT * 8 + BT + (size_t)BT * M)));
+  HIPCHK(dvox.alloc(sizeof(int) * (size_t)nvox));
+  {   // voxel of every slot of the class list (the identity without a list)
+    std::vector<int> hv(nvox);
+    for (int q = 0; q < nvox; ++q) hv[q] = h_list ? h_list[q] : q;
+    HIPCHK(hipMemcpyAsync(dvox.p, hv.data(), sizeof(int) * (size_t)nvox, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // (hv leaves scope; a pageable copy has returned by then anyway)
+  }
+  K3BArgs k{};
+  k.M = M; k.N = N; k.LD = LD;
+  k.A = dA.as<double>(); k.Y = d_Y; k.G = dG.as<double>();
+  k.nrm2 = dcol.as<double>(); k.aty = k.nrm2 + (size_t)BT * LD; k.ysq = k.aty + (size_t)BT * LD;
+  k.st3 = dst3.as<double2>();
+  k.thr = dsm.as<unsigned long long>(); k.seed = k.thr + BT; k.ncand = (int*)(k.seed + 7 * (size_t)BT);
+  k.dbg = k3dbg ? k.seed + 3 * (size_t)BT : nullptr;
+  k.cand_score = dcs.as<double>(); k.cand_tuple = dct.as<long>();
+  k.part = dpart.as<double>();
+  k.w = dout.as<double>(); k.sub = (long*)(k.w + (size_t)BT * 8); k.minobj = (double*)(k.sub + (size_t)BT * 8); k.yrec = k.minobj + BT;
+  const size_t lds = (size_t)2 * MFX_K3M_KB * (MFX_K3M_TI + MFX_K3M_TJ) * 64 * 16 + (size_t)(MFX_K3M_TI + MFX_K3M_TJ) * 32 * 16 +
+                     (size_t)2 * (MFX_K3M_TI + MFX_K3M_TJ) * 32 * MFX_K3M_KB * 12 + 2 * MFX_K3M_KB * 16 + 2 * MFX_K3M_Q * 4 + 16;
+  HIPCHK(hipFuncSetAttribute((const void*)mfx_k3b_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PackArgs pk{};
+  pk.M = M; pk.K = 3; pk.has_csf = 0; pk.E = 0; pk.maxfasc = maxfasc; pk.csf_on = csf_on; pk.ear_on = ear_on; pk.num_params = num_params;
+  if (k3dbg) HIPCHK(hipMemsetAsync(k.dbg, 0, sizeof(unsigned long long) * 4 * BT, st));
+  if (int rc = mfx_prof_begin(st)) return rc;
+  for (int q0 = 0; q0 < nvox; q0 += BT) {
+    const int B = std::min(BT, nvox - q0);
+    k.B = B; k.vox = dvox.as<int>() + q0;
+    for (int b = 0; b < B; ++b) {
+      const long v = h_list ? h_list[q0 + b] : q0 + b;
+      hipLaunchKernelGGL(mfx_rotate_kernel, dim3((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, 3), dim3(MFX_ROT_WG), 0, st, p->t->d, p->d,
+                         d_peaks + (size_t)v * peaks_ld, 0, dA.as<double>() + (size_t)b * M * LD, (long)N, (long)LD);
+    }
+    hipLaunchKernelGGL(mfx_k3b_stats_kernel, dim3((LD + 255) / 256, B), dim3(256), 0, st, k);
+    const int nt = (N + 63) / 64;
+    hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3(nt, nt, 3 * B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_pairs_kernel, dim3(256, B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_greedy_kernel, dim3(3, B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_screen_kernel, dim3((N + MFX_K3M_TJ * 32 - 1) / (MFX_K3M_TJ * 32), (N + MFX_K3M_TI * 32 - 1) / (MFX_K3M_TI * 32), B),
+                       dim3(MFX_K3M_TI * 64), lds, st, k);
+    hipLaunchKernelGGL(mfx_k3b_finalize_kernel, dim3(MFX_K3B_FW, B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_finish_kernel, dim3(B), dim3(256), 0, st, k, pk, d_params, num_params);
+    HIPCHK(hipGetLastError());
+    if (k3dbg) {   // developer diagnostics: synchronises
+      std::vector<unsigned long long> h(4 * (size_t)B + 0), ht(B);
+      std::vector<int> hn(2 * (size_t)B);
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(h.data(), k.dbg, sizeof(unsigned long long) * 4 * B, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ht.data(), k.thr, sizeof(unsigned long long) * B, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hn.data(), k.ncand, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b) {
+        double t0, t1;
+        memcpy(&t0, &h[4 * b + 3], 8); memcpy(&t1, &ht[b], 8);
+        fprintf(stderr, "[k3] slot %d: scored %llu (on the spot %llu, always-flag hits %llu), listed %d, threshold at screen start %.9g -> final %.9g (%.3e below)\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2],
+                hn[2 * b], t0, t1, (t1 - t0) / t1);
+      }
+      HIPCHK(hipMemsetAsync(k.dbg, 0, sizeof(unsigned long long) * 4 * B, st));
+    }
+  }
+  return mfx_prof_end(st);
 }
 
 // Three fascicles (BASELINE config 5; opt-in, MFModel.fit itself stops at two): no fused kernel yet - voxel after voxel

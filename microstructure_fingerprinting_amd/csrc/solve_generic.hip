@@ -326,8 +326,9 @@ struct PackArgs {
   int M, K, has_csf, E, maxfasc, csf_on, ear_on, num_params;
   double* out;   // the voxel's params row
 };
-__global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) {
-  const int lane = threadIdx.x, M = a.M;
+// (one wave: the 64 lanes of the calling wave)
+__device__ __forceinline__ void mfx_pack_params_body(const PackArgs& a) {
+  const int lane = threadIdx.x & 63, M = a.M;
   const int Kp = a.K + a.has_csf + (a.E > 0);
   double sy = 0.0, sr = 0.0;
   for (int m = lane; m < M; m += 64) { sy += a.y[m]; sr += a.yrec[m]; }
@@ -366,3 +367,4 @@ __global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) {
     a.out[a.num_params - 1] = r2;
   }
 }
+__global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) { mfx_pack_params_body(a); }

@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from microstructure_fingerprinting_amd import _lib as L
+if os.environ.get("MFX_DEV_LIB"):    # another build of the library (timing experiments)
+    L.LIB_PATH = os.path.abspath(os.environ["MFX_DEV_LIB"])
 from microstructure_fingerprinting_amd import engine, synth, mf_utils as mfu
 import bench
 dev = torch.device("cuda", 0)
