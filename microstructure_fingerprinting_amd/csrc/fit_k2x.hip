@@ -103,6 +103,13 @@ struct ProjB {   // threshold-independent part of the filter constants of one (a
   float np, zp;  // |d'| (0: d' vanishes, the atom passes with every partner) and d'.y' / |d'|
 };
 
+// d.f of a row / column with the atom's "passes with every partner" flags of the ntup tuples in its 16 lowest mantissa bits
+// (flag of tuple t in bit ntup - 1 - t: the layout of the filter's shift registers)
+__device__ __forceinline__ double mfx_pack_alw(double u, unsigned flags_by_tuple, int ntup) {
+  const unsigned rev = __builtin_bitreverse32(flags_by_tuple) >> (32 - ntup);
+  return __longlong_as_double((__double_as_longlong(u) & ~0xffffll) | (long long)rev);
+}
+
 struct CandX {   // short-list entry: a pair of atoms and its ranking score
   double score;
   int i, j;
@@ -342,17 +349,41 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   }
   __syncthreads();   // (workgroup-scope visibility of the slab, as for wsA)
   // for a threshold T: (P + D) |d'|, (1 - D) Q |d'| in FP32, P rounded up, Q down (only lets more pairs through)
-  auto proj_c = [&](const ProjB& pb, int t, double T) -> ProjC {
+  // (alw: the atom passes with EVERY partner for this tuple - its own projected score reaches the threshold, or it has no
+  // projection left.  The flags travel as bit masks in the low mantissa bits of the row's / column's d.f entry (s_rowf,
+  // s_colf: 16 of 52 bits of a ranking value) and are applied to the tests' sign bits in one instruction per row: a constant
+  // like pn = 1e18 works only while every partner's pn is positive, and an atom with a negative projection has pn < 0.)
+  auto proj_c = [&](const ProjB& pb, int t, double T, bool& alw) -> ProjC {
     ProjC c;
     c.u = pb.u;
     const float Tp = (float)(T - s_tc[4 * t + 3]) * (1.0f - 2e-7f);   // what the two projected atoms must reach (rounded down)
     const float z = pb.zp;
     const bool always = !(pb.np > 0.0f) || !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 1e-6f));
     const float rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 4e-7f);
-    const float P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
+    // P = cos theta over the WHOLE range of z (clamping z at 0 keeps the test valid but lets every sufficiently obtuse partner
+    // of an atom with a negative projection through; after the projection on the complement of the extra columns such atoms
+    // are common: fit_k3.hip counted 1e7 .. 3e8 false passes per voxel).  An atom whose projection on the signal is negative
+    // can still carry a positive weight beside a partner at an obtuse angle, and S(c) = T at c = cos(theta1 + theta2) holds
+    // for either sign (cos^2 a + cos^2 b - 2 cos(a + b) cos a cos b = sin^2(a + b)).
+    //  * Thresholds: the test is valid for atoms of either sign of z only if BOTH atoms' constants come from the same
+    //    threshold (for z > 0 a lower threshold lets more pairs through, for z < 0 - theta decreases with T - fewer): every
+    //    chunk has ONE threshold for all its constants, published in s_red[20 + chunk mod 3] two chunks ahead of its use:
+    //    the chunk's column constants are made from it, and every wave re-makes its row constants when it differs from theirs.
+    //  * Margin: at most one atom of a feasible pair has z < 0.  With P' = P + D, Q' = (1 - D) Q for the positive one and
+    //    P' = P + 2 D, Q' = Q - 2 D for the negative one,
+    //       P1' P2' - Q1' Q2' - (P1 P2 - Q1 Q2) = D (P1 + Q1 Q2) + 2 D (P2 + D) + 2 D (1 - D) Q2 >= D (-1 + 2 (P2 + Q2)) >= D
+    //    for theta1 in [90, 180] and theta2 in [0, 90] degrees (the folding for two positive z needs P1 + P2 + 1.99 Q1 Q2 >= 1,
+    //    which fails here; tests/test_parity_stress_gpu.py::test_k2x_flood_voxels_vs_oracle caught that).
+    const bool neg = !(z > 0.0f);
+    const float P = fmaxf(-1.0f, fminf(1.0f, z * rth));
     const float Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
-    c.pn = always ? 1e18f : (P + MFX_XD) * pb.np * (1.0f + 2e-7f);
-    c.qn = always ? 0.0f : Q * ((1.0f - MFX_XD) * pb.np) * (1.0f - 2e-7f);
+    float pnv = (P + (neg ? 2.0f * MFX_XD : MFX_XD)) * pb.np;
+    pnv += fabsf(pnv) * 2e-7f;                                    // rounded up
+    float qnv = neg ? (Q - 2.0f * MFX_XD) * pb.np : Q * ((1.0f - MFX_XD) * pb.np);
+    qnv -= fabsf(qnv) * 2e-7f;                                    // rounded down
+    c.pn = always ? 0.0f : pnv;
+    c.qn = always ? 0.0f : qnv;
+    alw = always;
     return c;
   };
 
@@ -367,9 +398,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     if (tid < 16 * MFX_XS) ga2x = wsA[((size_t)NP + ch * 16) * MFX_XS + tid];   // A2x of the chunk's 16 atoms
     const int c = tid & 15, m0 = tid >> 4;
     const int n = ch * 16 + c;
-    if (tid >= WG - 16 * (ntup + 1)) {   // filter base values of the chunk's columns: (column, tuple) and (column, fixed)
-      const int q = tid - (WG - 16 * (ntup + 1));
-      gpb = wsP[((size_t)NP + ch * 16) * (ntup + 1) + q];
+    if (tid >= WG - 256) {   // filter base values of the chunk's columns: 16 lanes per column, lane t: tuple t (t = ntup: the fixed column)
+      const int q = tid - (WG - 256), cc = q >> 4, t = q & 15;
+      if (t <= ntup) gpb = wsP[((size_t)NP + ch * 16 + cc) * (ntup + 1) + t];
     }
 #pragma unroll
     for (int p = 0; p < NEL; ++p) {
@@ -400,15 +431,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       }
     }
     if (tid < 16 * MFX_XS) s_a2x[buf * 16 * MFX_XS + tid] = ga2x;
-    if (tid >= WG - 16 * (ntup + 1)) {   // filter constants of the chunk's columns for the current threshold
-      const int q = tid - (WG - 16 * (ntup + 1));
-      const int cc = q / (ntup + 1), t = q - cc * (ntup + 1);
-      if (t == ntup) {
-        s_colf[buf * 16 + cc] = gpb.u;
-      } else {
-        const double T = __longlong_as_double((long long)s_thr[0]) - eps_abs_of * y_sq;
-        s_colc[(buf * 16 + cc) * ntup + t] = proj_c(gpb, t, T);
-      }
+    if (tid >= WG - 256) {   // filter constants of the chunk's columns for the current threshold (whole waves: ballot below)
+      const int q = tid - (WG - 256), cc = q >> 4, t = q & 15;
+      bool alw = false;
+      if (t < ntup) s_colc[(buf * 16 + cc) * ntup + t] = proj_c(gpb, t, s_red[20 + ch % 3], alw);   // the chunk's threshold
+      const unsigned long long am = __builtin_amdgcn_ballot_w64(alw);
+      if (t == ntup) s_colf[buf * 16 + cc] = mfx_pack_alw(gpb.u, (unsigned)(am >> (lane & 48)) & 0xffffu, ntup);
     }
   };
   auto gen_chunk = [&](int ch, int buf) { gen_load(ch); gen_store(ch, buf); };
@@ -440,26 +468,31 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     double thr_rows = -INFINITY;   // (T = threshold - 1e-9 |y|^2 is below -1 for a large weak signal: no finite sentinel)
     auto row_consts = [&](double T) {
       thr_rows = T;
-      for (int q = lane; q < 16 * (ntup + 1); q += 64) {
-        const int il = q / (ntup + 1), t = q - il * (ntup + 1);
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {   // 16 lanes per row, lane t: tuple t (t = ntup: the fixed column)
+        const int il = 4 * it + (lane >> 4), t = lane & 15;
         ProjB pb;
         pb.u = 0.0; pb.np = 0.0f; pb.zp = 0.0f;
-        if (rt_valid) pb = wsP[((size_t)rt * 16) * (ntup + 1) + q];   // (atoms beyond N: np = 0, they pass and are skipped by the scan)
-        if (t == ntup) s_rowf[wave * 16 + il] = pb.u;
-        else s_rowc[(wave * 16 + il) * ntup + t] = proj_c(pb, t, T);
+        if (rt_valid && t <= ntup) pb = wsP[((size_t)rt * 16 + il) * (ntup + 1) + t];   // (atoms beyond N: np = 0, they pass and are skipped by the scan)
+        bool alw = false;
+        if (t < ntup) s_rowc[(wave * 16 + il) * ntup + t] = proj_c(pb, t, T, alw);
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(alw);
+        if (t == ntup) s_rowf[wave * 16 + il] = mfx_pack_alw(pb.u, (unsigned)(am >> (lane & 48)) & 0xffffu, ntup);
       }
       __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations execute in order: its later reads see these writes)
     };
 
     if (round == 0) MFX_STAMP(3);
+    if (tid == 0) s_red[20] = s_red[21] = __longlong_as_double((long long)s_thr[0]) - eps_abs;   // thresholds of chunks 0 and 1 (slot = chunk mod 3)
+    __syncthreads();
     gen_chunk(0, 0);
     __syncthreads();
     if (round == 0) MFX_STAMP(4);
     for (int ch = 0; ch < ntiles; ++ch) {
       const int buf = (NBUF == 2) ? (ch & 1) : 0;
       {
-        const double T = __longlong_as_double((long long)s_thr[0]) - eps_abs;
-        if (T > thr_rows && (ch & 3) == 0) row_consts(T);
+        const double T = s_red[20 + ch % 3];   // the chunk's threshold (its column constants were made from it)
+        if (T != thr_rows) row_consts(T);
       }
 #ifdef MFX_STAMPS_W   // diagnostic: where a chunk's time goes (chunk 10 of round 1; waves 0 and 7), tools/dev_stamps_k2x.py w
 #define MFX_XSTAMP(k) do { if (a.stamps && round == 1 && ch == 10 && (tid == 0 || tid == WG - 64)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -509,8 +542,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
           const ProjC* rc = s_rowc + (wave * 16 + lg) * ntup;
           const double uf2 = s_colf[buf * 16 + lc];
           double accf[4];
+          unsigned alwm[4];   // tuples this pair passes whatever the test says (bit layout of fm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) accf[r] = HASF ? fma(-s_rowf[wave * 16 + lg + 4 * r], uf2, acc[r]) : acc[r];
+          for (int r = 0; r < 4; ++r) {
+            const double uf1 = s_rowf[wave * 16 + lg + 4 * r];
+            accf[r] = HASF ? fma(-uf1, uf2, acc[r]) : acc[r];
+            alwm[r] = ((unsigned)__double_as_longlong(uf1) | (unsigned)__double_as_longlong(uf2)) & 0xffffu;
+          }
           const ProjC* r0p = rc, *r1p = rc + 4 * ntup, *r2p = rc + 8 * ntup, *r3p = rc + 12 * ntup;
 #pragma unroll 2
           for (int t = 0; t < ntup; ++t) {
@@ -526,6 +564,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
             fm[2] = __builtin_amdgcn_alignbit(fm[2], __float_as_uint(b2), 31);
             fm[3] = __builtin_amdgcn_alignbit(fm[3], __float_as_uint(b3), 31);
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fm[r] &= ~alwm[r];
         }
         // ---- the passing tuples of the wave's 256 pairs are COMPACTED before they are scored: a few percent of the
         // tuples pass, scattered over the lanes - scored in place, the ~100-instruction FP64 scoring ran for almost every
@@ -692,6 +732,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         }
       }
       MFX_XSTAMP(4);
+      // the threshold of chunk ch + 2 (its column constants are made during chunk ch + 1, after this barrier); its slot held
+      // chunk ch - 1's, last read before the barrier that ended that chunk
+      if (tid == 0) s_red[20 + (ch + 2) % 3] = __longlong_as_double((long long)s_thr[0]) - eps_abs;
       __syncthreads();
       MFX_XSTAMP(5);
     }

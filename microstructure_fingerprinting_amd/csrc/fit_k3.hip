@@ -335,7 +335,11 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
             // sin^2(a+b)); clamping z at 0 (solve_k3.hip) keeps the test valid but lets every sufficiently obtuse pair of
             // such an atom through: 1e7 .. 3e8 triples per voxel in voxels with a flat optimum.  The margin D |d1'||d2'| has
             // its own k-slot (the folding of fit_k2s.hip assumes P >= 0).
-            const float Pc = fmaxf(-1.0f, fminf(1.0f, z * rth));
+            // (the threads of a block read the running threshold one by one: two items of one test may have seen different
+            // values.  For z > 0 a lower threshold only lets more through; for z < 0 - theta decreases with T - it is the
+            // other way round, so a negative z uses an upper bound of every threshold: the projected signal's energy)
+            const float rub = __builtin_amdgcn_rsqf(fmaxf((float)(y_sq - z3 * z3) * (1.0f + 2e-7f), 1e-30f)) * (1.0f - 4e-7f);
+            const float Pc = z > 0.0f ? fminf(1.0f, z * rth) : fmaxf(-1.0f, z * rub);
             const float Qc = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-Pc, Pc, 1.0f)));
             P = Pc * npf;
             Qv = Qc * npf;
