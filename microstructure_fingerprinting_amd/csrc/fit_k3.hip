@@ -202,6 +202,7 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
   float* s_b3 = s_uu + 2 * (TI + TJ) * 32 * KB;            // [2][KB][4] per third atom: T - z3^2, z3 = y.d3/|d3|, -, -
   unsigned* s_q = (unsigned*)(s_b3 + 2 * KB * 4);          // [2][MFX_K3M_Q] passing triples: (i local << 9) | (j local << 2) | kk
   int* s_qn = (int*)(s_q + 2 * MFX_K3M_Q);                 // [2]
+  double* s_T = (double*)(s_qn + 2);                       // [3] the threshold of block b in slot b mod 3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, N = k.N;
   const long nn = (long)N * N;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
     s_ay[q] = ok ? ay[side ? N + a : a] : 0.0;
   }
   if (tid < 2) s_qn[tid] = 0;
+  if (tid == 0) s_T[0] = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
   if (k.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) k.dbg[4 * b + 3] = *thrp;
   __syncthreads();
   // accumulator inputs of this wave's four tile pairs: -a12 + margin |d1||d2|, rounded up; -1e30 where there is no pair
@@ -305,8 +307,10 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
 #else
     if (blk < nblk) {
 #endif
-      // ---- operands of the block from the CURRENT threshold: (TI + TJ) x 32 atoms x KB third atoms, 3 items per thread
-      const double T = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
+      // ---- operands of the block from ONE recent threshold (read by thread 0 a block ahead, behind a barrier):
+      // (TI + TJ) x 32 atoms x KB third atoms, 3 items per thread
+      const double T = s_T[blk % 3];
+      if (tid == 0) s_T[(blk + 1) % 3] = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
       for (int q = tid; q < (TI + TJ) * 32 * KB; q += WGS) {
         const int kk = q & (KB - 1), al = q / KB;            // al: atom within the workgroup (i1 side first)
         const bool side = al >= TI * 32;
@@ -335,11 +339,10 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
             // sin^2(a+b)); clamping z at 0 (solve_k3.hip) keeps the test valid but lets every sufficiently obtuse pair of
             // such an atom through: 1e7 .. 3e8 triples per voxel in voxels with a flat optimum.  The margin D |d1'||d2'| has
             // its own k-slot (the folding of fit_k2s.hip assumes P >= 0).
-            // (the threads of a block read the running threshold one by one: two items of one test may have seen different
-            // values.  For z > 0 a lower threshold only lets more through; for z < 0 - theta decreases with T - it is the
-            // other way round, so a negative z uses an upper bound of every threshold: the projected signal's energy)
-            const float rub = __builtin_amdgcn_rsqf(fmaxf((float)(y_sq - z3 * z3) * (1.0f + 2e-7f), 1e-30f)) * (1.0f - 4e-7f);
-            const float Pc = z > 0.0f ? fminf(1.0f, z * rth) : fmaxf(-1.0f, z * rub);
+            // (valid for either sign of z only if both atoms of a test see the SAME threshold - for z > 0 a lower threshold
+            // lets more pairs through, for z < 0, where theta decreases with T, fewer: all items of a block are built from
+            // one value, s_T[block mod 3], published a block ahead)
+            const float Pc = fmaxf(-1.0f, fminf(1.0f, z * rth));
             const float Qc = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-Pc, Pc, 1.0f)));
             P = Pc * npf;
             Qv = Qc * npf;
