@@ -51,7 +51,7 @@ C4_E = 10
 FLOP_PER_VOXEL_C4 = 244.6e6 + 782.0 * 782.0 * C4_E * 150.0
 # config 5, sub-dictionaries [1500, 1500, 1500] x 300 measurements: three N x N cross-Grams + N^3 three-column solves of the
 # reference's solve_exhaustive_posweights_3 (Cramer 3x3 + residual from the Gram scalars: ~40 flops each, mf_utils.py:540-600)
-C5_N, C5_V = 1500, 16
+C5_N, C5_V = 1500, 64
 FLOP_PER_VOXEL_C5 = 3 * 2.0 * C5_N * C5_N * 300 + 40.0 * float(C5_N) ** 3
 PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_k2s.json")
 PMC_C4 = os.path.join("profiles", "r02_pmc_k2x.json")
@@ -478,28 +478,31 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
                  "unit": "voxels/s", "kernel": "mfx_fit_small_kernel<false>", "kernel_us": round(kms * 1e3, 1) if kms else None,
                  "bound": "launch latency (one 1000-workgroup launch; HBM roofline for reference)",
                  "achieved_GBps": round(byt / dt / 1e9, 3), "peak_GBps": PEAK_HBM_GBPS, "frac": round(byt / dt / 1e9 / PEAK_HBM_GBPS, 6)}
-    # ---- config 5: three fascicles, 1500 atoms x 300 measurements (3.4e9 triples per voxel), rotated dictionaries materialised
-    # per voxel, explicit-dictionary solver with the relaxed-bound triple screen (solve_k3.hip); opt-in maxfasc = 3
+    # ---- config 5: three fascicles, 1500 atoms x 300 measurements (3.4e9 triples per voxel), the dictionary sampled on the
+    # subject's own protocol and rotated per voxel with rotate_atom's tables (mf_utils.py:1205-1437: an explicit row plan with
+    # the free-diffusion knot, DIFF = 2e-9, S0 = the atoms' b0 signal), as BASELINE words config 5; batched three-fascicle path
+    # (fit_k3.hip: rotation, Gram cross blocks on FP64 MFMA, triple screen on FP16 MFMA, exact finalize); opt-in maxfasc = 3
     rng5 = np.random.default_rng(5)
     sch5 = synth.make_scheme(rng5, 1, [1000, 2000, 3000, 4000], [75, 75, 75, 74])
     dic5 = synth.make_dictionary(rng5, sch5, C5_N)
-    ms5 = mfu.init_PGSE_multishell_interp(dic5, sch5, np.array([0.0, 0.0, 1.0]))
-    ms5.device = dev.index or 0
-    plan5 = engine.Plan(ms5.device_tables(), scheme=sch5)
+    S05 = np.ascontiguousarray(np.repeat(dic5[:1, :], sch5.shape[0], axis=0))      # b0 signal of every atom, constant within a shell
+    rt5 = mfu.RotateAtomTables(np.ascontiguousarray(dic5), sch5, np.array([0.0, 0.0, 1.0]), 2.0e-9, S05, warnings=False, device=dev.index or 0)
+    plan5 = rt5.plan
     _, d_pk5, d_Y5 = synth_voxels(plan5, C5_V, C5_N, sch5.shape[0], dev, 7, K=3)
     o5 = torch.zeros((C5_V, engine.num_params(3, False, False)), dtype=torch.float64, device=dev)
     dt, kms = timed(lambda: L.check(lib.mfx_fit_batch_dev(plan5.handle(), d_Y5.data_ptr(), d_pk5.data_ptr(), 3, 0, 0, None, None, 0,
                                                          C5_V, o5.data_ptr(), st)), 2, 1, dev, lib)
     ach = FLOP_PER_VOXEL_C5 * C5_V / dt / 1e12
-    out["c5"] = {"workload": "C5: %d voxels, 3 fascicles, sub-dictionaries [%d, %d, %d], %d measurements (%.2e triples per voxel)"
+    out["c5"] = {"workload": "C5: %d voxels, 3 fascicles, sub-dictionaries [%d, %d, %d], %d measurements (%.2e triples per voxel), explicit rotate_atom plan"
                              % (C5_V, C5_N, C5_N, C5_N, sch5.shape[0], float(C5_N) ** 3),
                  "value": round(C5_V / dt, 1), "unit": "voxels/s", "ms_per_voxel": round(dt / C5_V * 1e3, 3),
-                 "kernel": "mfx_k3_screen_kernel (+ mfx_k3_gram_kernel, mfx_tuple_finalize), two voxels in flight", "bound": "valu issue",
+                 "kernel": "mfx_k3b_screen_kernel (+ mfx_k3b_gram_kernel, mfx_k3b_finalize_kernel), batches of 8 voxels", "bound": "valu issue",
                  "reference_flop_per_voxel": FLOP_PER_VOXEL_C5, "reference_TFLOPs_equivalent": round(ach, 2),
                  "reference_TFLOPs_is": "the REFERENCE's work (three cross-Grams + N^3 three-column solves of ~40 flop) per second; the "
-                                        "screen decides a triple in ~11 FP32 instructions, so this is NOT a utilisation",
-                 "issue_utilisation_pmc": _pmc_field(PMC_C5, "issue_utilisation"), "pmc_from": PMC_C5 if os.path.exists(os.path.join(ROOT, PMC_C5)) else None}
-    del plan5, d_Y5, d_pk5, o5
+                                        "screen decides 1024 triples with one FP16 MFMA and ~12 FP32 instructions, so this is NOT a utilisation",
+                 "issue_utilisation_pmc": _pmc_field(PMC_C5, "issue_utilisation"), "mfma_pipe_utilisation_pmc": _pmc_field(PMC_C5, "mfma_pipe_utilisation"),
+                 "pmc_from": PMC_C5 if os.path.exists(os.path.join(ROOT, PMC_C5)) else None}
+    del plan5, rt5, d_Y5, d_pk5, o5
     # ---- PCIe-inclusive: the host entry point (pinned double-buffered upload overlapped with the kernels), NumPy buffers in and out
     Yh, pkh = d_Y.cpu().numpy(), np.ascontiguousarray(peaks_h)
     Kh = np.full(V, 2, dtype=np.int32)

@@ -191,6 +191,9 @@ int mfx_debug_last_guard_count(void);
  * with its FP64 value, listed or not): 8 audited pairs whose error exceeds a quarter of the screening margin, 9 the largest
  * error in units of 1e-11 (cosine units), 10 audited pairs; which = 0..11. */
 int mfx_debug_last_counter(int which);
+/* Diagnostic: candidate-list entries per voxel of the batched three-fascicle path (fit_k3.hip; 0: the built-in 4 M).  A voxel
+ * whose list overflows is redone by the voxel-by-voxel path, gated on the device; tests lower the cap to force that. */
+void mfx_debug_set_k3_cap(int cap);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: 1 routes two-fascicle voxels of protocols with 129..256 measurements to the wide (one wave per SIMD)

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     //    P' = P + 2 D, Q' = Q - 2 D for the negative one,
     //       P1' P2' - Q1' Q2' - (P1 P2 - Q1 Q2) = D (P1 + Q1 Q2) + 2 D (P2 + D) + 2 D (1 - D) Q2 >= D (-1 + 2 (P2 + Q2)) >= D
     //    for theta1 in [90, 180] and theta2 in [0, 90] degrees (the folding for two positive z needs P1 + P2 + 1.99 Q1 Q2 >= 1,
-    //    which fails here; tests/test_parity_stress_gpu.py::test_k2x_flood_voxels_vs_oracle caught that).
+    //    which fails here: the flood-voxel parity test caught that).
     const bool neg = !(z > 0.0f);
     const float P = fmaxf(-1.0f, fminf(1.0f, z * rth));
     const float Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);

@@ -56,6 +56,7 @@ typedef float k3_f16v __attribute__((ext_vector_type(16)));
 
 struct K3BArgs {
   int B, M, N, LD;                 // voxels in the batch, measurements, atoms per dictionary, 3 N
+  int cap;                         // candidate list entries in use (<= MFX_K3B_CAP; tests lower it to force the fallback)
   const double* A;                 // [B][M][LD] rotated dictionaries, row-major
   const double* Y;                 // signals of all voxels [V][M]
   const int* vox;                  // [B] voxel of slot b
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
     const double Tn = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
     if (s >= Tn && s > 0.0) {
       const int slot = atomicAdd(&k.ncand[2 * b], 1);
-      if (slot < MFX_K3B_CAP) {
+      if (slot < k.cap) {
         k.cand_score[(size_t)b * MFX_K3B_CAP + slot] = s;
         k.cand_tuple[(size_t)b * MFX_K3B_CAP + slot] = ((long)i * N + j) * N + k3;   // itertools order: last index fastest
       } else {
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void mfx_k3b_finalize_kernel(K3BArgs k) {
   const double* __restrict__ A = k.A + (size_t)b * M * LD;
   const double* __restrict__ y = k.Y + (size_t)k.vox[b] * M;
   const double y_sq = k.ysq[2 * b];
-  const int nc = min(k.ncand[2 * b], MFX_K3B_CAP);
+  const int nc = min(k.ncand[2 * b], k.cap);
   // (every raise of the threshold comes with a listed triple of that score - the seed's triples are found again by the
   // screen - so the threshold IS the list's maximum)
   const double thr = __longlong_as_double((long long)k.thr[b]) - 1e-9 * y_sq;

@@ -220,6 +220,7 @@ extern "C" void mfx_debug_set_k2x_screen(int on) { mfx_thread().k2x_screen = on 
 extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (unsigned long long*)dev_ptr; }
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
 extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }
+extern "C" void mfx_debug_set_k3_cap(int cap) { mfx_thread().k3_cap = cap > 0 ? cap : 0; }
 extern "C" void mfx_debug_set_k2s_images(int nb) { mfx_thread().k2s_nb = (nb == 2) ? 2 : 0; }
 extern "C" void mfx_debug_set_k2s_cap(int cap) {
   int c = 4;
@@ -731,6 +732,7 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   }
   K3BArgs k{};
   k.M = M; k.N = N; k.LD = LD;
+  k.cap = (mfx_thread().k3_cap > 0 && mfx_thread().k3_cap < MFX_K3B_CAP) ? mfx_thread().k3_cap : MFX_K3B_CAP;
   k.A = dA.as<double>(); k.Y = d_Y; k.G = dG.as<double>();
   k.nrm2 = dcol.as<double>(); k.aty = k.nrm2 + (size_t)BT * LD; k.ysq = k.aty + (size_t)BT * LD;
   k.st3 = dst3.as<double2>();
@@ -745,6 +747,24 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   PackArgs pk{};
   pk.M = M; pk.K = 3; pk.has_csf = 0; pk.E = 0; pk.maxfasc = maxfasc; pk.csf_on = csf_on; pk.ear_on = ear_on; pk.num_params = num_params;
   if (k3dbg) HIPCHK(hipMemsetAsync(k.dbg, 0, sizeof(unsigned long long) * 4 * BT, st));
+  // fallback of a candidate-list overflow (a voxel with more than MFX_K3B_CAP triples within 1e-9 |y|^2 of its optimum): the
+  // voxel-by-voxel path of solve_k3.hip (itself backed by the full scan), enqueued for EVERY slot of a batch and gated on the
+  // device by the slot's overflow flag - no host read; an idle launch sequence costs ~25 us per voxel
+  StreamMem fG(st), fcol(st), fbs(st), fbt(st), fout(st), fk3(st);
+  SolveArgs fa{};
+  for (int q = 0; q < 3; ++q) { fa.sizes[q] = N; fa.start[q] = (long)q * N; }
+  fa.M = M; fa.Kp = 3; fa.Ntot = LD; fa.lda = LD; fa.ntuples = (long)N * N * N;
+  fa.nblocks = (int)std::min<long>(16384, (fa.ntuples + 255) / 256);
+  HIPCHK(fG.alloc(sizeof(double) * (size_t)LD * LD));
+  HIPCHK(fcol.alloc(sizeof(double) * ((size_t)LD + 2)));
+  HIPCHK(fbs.alloc(sizeof(double) * (size_t)MFX_K3_CAP));
+  HIPCHK(fbt.alloc(sizeof(long) * (size_t)MFX_K3_CAP));
+  HIPCHK(fout.alloc(sizeof(double) * (MFX_GK + MFX_GK + 1 + (size_t)M)));
+  HIPCHK(fk3.alloc(k3_buf_bytes(N)));
+  fa.G = fG.as<double>(); fa.Aty = fcol.as<double>(); fa.ysq = fa.Aty + LD;
+  fa.blk_score = fbs.as<double>(); fa.blk_tuple = fbt.as<long>();
+  fa.w = fout.as<double>(); fa.sub = (long*)(fa.w + MFX_GK); fa.minobj = (double*)(fa.sub + MFX_GK); fa.yrec = fa.minobj + 1;
+  const K3Bufs fkb = k3_bufs(fk3.as<char>());
   if (int rc = mfx_prof_begin(st)) return rc;
   for (int q0 = 0; q0 < nvox; q0 += BT) {
     const int B = std::min(BT, nvox - q0);
@@ -763,6 +783,19 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
                        dim3(MFX_K3M_TI * 64), lds, st, k);
     hipLaunchKernelGGL(mfx_k3b_finalize_kernel, dim3(MFX_K3B_FW, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_finish_kernel, dim3(B), dim3(256), 0, st, k, pk, d_params, num_params);
+    HIPCHK(hipGetLastError());
+    for (int b = 0; b < B; ++b) {   // gated fallback (see above)
+      const long v = h_list ? h_list[q0 + b] : q0 + b;
+      fa.A = dA.as<double>() + (size_t)b * M * LD;
+      fa.y = d_Y + (size_t)v * M;
+      fa.run_if = k.ncand + 2 * b + 1;
+      if (int rc = launch_solver(fa, &fkb, st)) return rc;
+      PackArgs pa = pk;
+      pa.run_if = fa.run_if;
+      pa.w = fa.w; pa.sub = fa.sub; pa.minobj = fa.minobj; pa.yrec = fa.yrec; pa.y = fa.y;
+      pa.out = d_params + (size_t)v * num_params;
+      hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, st, pa);
+    }
     HIPCHK(hipGetLastError());
     if (k3dbg) {   // developer diagnostics: synchronises
       std::vector<unsigned long long> h(4 * (size_t)B + 0), ht(B);

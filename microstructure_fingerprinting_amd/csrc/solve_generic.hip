@@ -35,6 +35,8 @@ struct SolveArgs {
   const int* nblocks_dev;   // device-side number of entries in blk_score / blk_tuple (< 0: use nblocks)
   const int* scan_enable;   // the full scan below runs only when this device flag is set
   int gram_ranking_only;    // G was summed on the matrix pipe: the finalize stage re-sums what it needs sequentially
+  const int* run_if;        // null, or a device flag: every kernel of the launch sequence exits at once while it is 0 (fit_k3.hip
+                            // enqueues this path for every voxel of a batch as the fallback of a candidate-list overflow)
   // outputs
   double* w;       // [Kp]
   long* sub;       // [Kp]
@@ -43,6 +45,7 @@ struct SolveArgs {
 };
 
 __global__ void mfx_gram_kernel(SolveArgs a) {
+  if (a.run_if && !*a.run_if) return;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nn = (long)a.Ntot * a.Ntot;
   if (idx < nn) {
@@ -138,6 +141,7 @@ __device__ inline double mfx_tuple_score(const SolveArgs& a, const int col[MFX_G
 __global__ __launch_bounds__(256) void mfx_tuple_scan(SolveArgs a) {
   __shared__ double s_sc[256];
   __shared__ long s_t[256];
+  if (a.run_if && !*a.run_if) return;
   if (a.scan_enable && !*a.scan_enable) return;   // (three-dictionary fast path: only after a candidate-list overflow)
   double best = 0.0;
   long bt = -1;
@@ -169,6 +173,7 @@ __device__ __forceinline__ long mfx_order_key(const SolveArgs& a, long t) {
 }
 
 __global__ __launch_bounds__(256) void mfx_tuple_finalize(SolveArgs a) {
+  if (a.run_if && !*a.run_if) return;
   __shared__ double s_res[256];
   __shared__ long s_key[256], s_tt[256];
   __shared__ double s_w[256][MFX_GK];
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(256) void mfx_tuple_finalize(SolveArgs a) {
 
 // ---- params packing for the voxel loop's generic classes (mf.py:420-450) from the solver's outputs: one 64-thread workgroup
 struct PackArgs {
+  const int* run_if;   // null, or a device flag: the kernel exits at once while it is 0
   const double* w; const long* sub; const double* minobj; const double* yrec; const double* y;
   int M, K, has_csf, E, maxfasc, csf_on, ear_on, num_params;
   double* out;   // the voxel's params row
@@ -367,4 +373,7 @@ __device__ __forceinline__ void mfx_pack_params_body(const PackArgs& a) {
     a.out[a.num_params - 1] = r2;
   }
 }
-__global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) { mfx_pack_params_body(a); }
+__global__ __launch_bounds__(64) void mfx_pack_params_kernel(PackArgs a) {
+  if (a.run_if && !*a.run_if) return;
+  mfx_pack_params_body(a);
+}

@@ -45,6 +45,7 @@ struct K3Args {
 
 // ---- 1. Gram on FP64 MFMA: one wave = 16 rows x 64 columns of G, 256-thread workgroups = 4 waves = 64 x 64
 __global__ __launch_bounds__(256) void mfx_k3_gram_kernel(SolveArgs a) {
+  if (a.run_if && !*a.run_if) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4, lc = lane & 15;
   const int N = a.Ntot, M = a.M;
   const int p0 = blockIdx.y * 64 + wave * 16, q0 = blockIdx.x * 64;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void mfx_k3_gram_kernel(SolveArgs a) {
 
 // A^T y and |y|^2 (sequential sums, as the generic Gram kernel computes them)
 __global__ void mfx_k3_aty_kernel(SolveArgs a) {
+  if (a.run_if && !*a.run_if) return;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < a.Ntot) {
     double s = 0.0;
@@ -96,6 +98,7 @@ __device__ __forceinline__ void k3_raise(unsigned long long* thr, double s) {
 
 // per atom of dictionary 3: 1/|d3| and y.d3/|d3| (used by every (atom, i3) item of the screen)
 __global__ void mfx_k3_st3_kernel(K3Args k) {
+  if (k.s.run_if && !*k.s.run_if) return;
   const SolveArgs& a = k.s;
   const int k3 = blockIdx.x * blockDim.x + threadIdx.x;
   if (k3 < a.sizes[2]) {
@@ -107,6 +110,7 @@ __global__ void mfx_k3_st3_kernel(K3Args k) {
 
 // ---- 2. threshold start: best support with at most two atoms
 __global__ __launch_bounds__(256) void mfx_k3_pairs_kernel(K3Args k) {
+  if (k.s.run_if && !*k.s.run_if) return;
   const SolveArgs& a = k.s;
   const long N1 = a.sizes[0], N2 = a.sizes[1], N3 = a.sizes[2];
   const long n12 = N1 * N2, n13 = N1 * N3, n23 = N2 * N3;
@@ -140,6 +144,7 @@ __device__ __forceinline__ K3C k3_ldc(const K3C* p) {
 }
 
 __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
+  if (k.s.run_if && !*k.s.run_if) return;
   const SolveArgs& a = k.s;
   // [side][atom][i3 in block], 65 KB; the atom stride is padded by one entry: a thread's column constants sit 1 040 bytes
   // apart (without it: 1 024 bytes, a 32-way bank conflict on every read - the screen was bound by the LDS, 2.8 of 4.3 ms)
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256) void mfx_k3_screen_kernel(K3Args k) {
 
 // candidate list -> the generic finalize's view: nblocks = number of candidates (device side)
 __global__ void mfx_k3_publish_kernel(K3Args k, int* nblocks_dev) {
+  if (k.s.run_if && !*k.s.run_if) return;
   if (threadIdx.x == 0) {
     const int n = k.ncand[0];
     nblocks_dev[0] = (k.ncand[1] || n > MFX_K3_CAP) ? -1 : n;   // -1: overflow, the full scan's per-block results are used

@@ -759,6 +759,38 @@ def test_three_fascicles_oracle_refereed_at_n400():
         assert np.isclose(got[v, -2], mo / M, rtol=1e-9, atol=1e-12 * float(Y[v] @ Y[v]) / M), (v, kinds[v], got[v, -2] * M, mo)
 
 
+def test_three_fascicles_batched_path_overflow_fallback():
+    """The batched three-fascicle path (fit_k3.hip) with its candidate list cut to 4 entries: every voxel overflows and is
+    redone by the voxel-by-voxel path, enqueued behind the batch and gated on the device by the overflow flag.  Results
+    must equal the un-cut run's (which the oracle referees in the tests above), incl. a one-atom signal whose N^2 ties fill
+    any list."""
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    rng = np.random.default_rng(78)
+    sch = synth.make_scheme(rng, 1, [1000, 2000, 3000], [40, 40, 39])
+    N, M, V = 96, sch.shape[0], 11
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    peaks = np.concatenate([synth.unit_vectors(rng, V) for _ in range(3)], axis=1)
+    atoms = rng.integers(0, N, (V, 3))
+    nu = rng.dirichlet(np.ones(3) * 2, V)
+    nu[3] = [0.0, 1.0, 0.0]
+    Y = rng.normal(0, 500.0 / 30.0, (V, M))
+    for k in range(3):
+        Y += 500.0 * nu[:, k:k + 1] * _rotate_cols(plan, peaks[:, 3 * k:3 * k + 3], atoms[:, k])
+    lib = L.lib()
+    full = engine.fit_batch(plan, Y, np.full(V, 3), None, None, peaks, 3, False, False)
+    try:
+        lib.mfx_debug_set_k3_cap(4)
+        cut = engine.fit_batch(plan, Y, np.full(V, 3), None, None, peaks, 3, False, False)
+    finally:
+        lib.mfx_debug_set_k3_cap(0)
+    assert np.array_equal(full[:, 4:7], cut[:, 4:7]), (full[:, 4:7], cut[:, 4:7])
+    assert np.allclose(full, cut, rtol=1e-12, atol=1e-12)
+
+
 def test_c5_full_size_properties():
     """BASELINE config 5 at its full size - three fascicles, 1500 atoms x 300 measurements, 3.4e9 triples per voxel -
     through mfx_fit_batch_dev (two voxels in flight).  The oracle would need hours per voxel here, so the checks are
