@@ -53,9 +53,9 @@ FLOP_PER_VOXEL_C4 = 244.6e6 + 782.0 * 782.0 * C4_E * 150.0
 # reference's solve_exhaustive_posweights_3 (Cramer 3x3 + residual from the Gram scalars: ~40 flops each, mf_utils.py:540-600)
 C5_N, C5_V = 1500, 64
 FLOP_PER_VOXEL_C5 = 3 * 2.0 * C5_N * C5_N * 300 + 40.0 * float(C5_N) ** 3
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_k2s.json")
-PMC_C4 = os.path.join("profiles", "r02_pmc_k2x.json")
-PMC_C5 = os.path.join("profiles", "r02_pmc_c5_screen.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_traffic_k2s.json")
+PMC_C4 = os.path.join("profiles", "r03_pmc_k2x.json")
+PMC_C5 = os.path.join("profiles", "r03_pmc_k3_screen.json")
 
 
 def _pmc_field(rel, key):

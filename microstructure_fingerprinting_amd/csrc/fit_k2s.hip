@@ -162,7 +162,11 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
   int bn1 = 0;
   const int nrounds = (ntiles + NW - 1) / NW;
   // the voxel's audited pair (k2s_shared.h): its row tile and column chunk; the shared last row tile is not audited
+#ifdef MFX_EXP_NOAUDIT   // timing experiment
+  const int aud_key = -1;
+#else
   const int aud_key = (!XC && a.audit) ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
+#endif
   for (int round = 0; round < nrounds; ++round) {
     // A last round with ONE row tile left (N = 782: 25 = 3*8 + 1) is shared by all waves: each keeps the same
     // A tile and takes every 8th column tile, generating its B operand straight into registers (no LDS image,

@@ -6,7 +6,7 @@ import collections, csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kern = sys.argv[1] if len(sys.argv) > 1 else "mfx_fit_k2s_kernel"
 tag = sys.argv[2] if len(sys.argv) > 2 else "k2s"
-rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+rnd = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 res = collections.defaultdict(float)
 # gpurun merges new outputs into gpurun_out/ without removing older ones: take the newest run of every counter group
 for d in glob.glob(R + '/gpurun_out/prof_pmc_*/runc'):
@@ -35,6 +35,10 @@ out = {"round": rnd,
        "kernel_cycles_per_xcd": cyc_xcd, "cu_cycles_per_voxel": cyc_xcd * 256 / V,
        "mfma_pipe_utilisation": res['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc_xcd,
        "valu_insts_per_mfma": res['SQ_INSTS_VALU'] / max(res['SQ_INSTS_MFMA'], 1),
+       # vector-issue slots in use: a wave64 vector instruction takes 4 issue cycles of its SIMD (MI355X_MICROARCH.md, 'vector-
+       # instruction ISSUE cost'; FP64 and transcendental ones more - a lower bound), an MFMA 8; 4 SIMDs x CU-cycles are available
+       "issue_utilisation": (4.0 * res['SQ_INSTS_VALU'] + 8.0 * res['SQ_INSTS_MFMA']) / max(4.0 * cyc_xcd * 256, 1),
+       "issue_utilisation_is": "(4 SQ_INSTS_VALU + 8 SQ_INSTS_MFMA) / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8)",
        "lds_bank_conflict_cycles_per_voxel": res.get('SQ_LDS_BANK_CONFLICT', 0) / V,
        "lds_bank_conflict_frac_of_lds_active": res.get('SQ_LDS_BANK_CONFLICT', 0) / max(res.get('SQ_LDS_IDX_ACTIVE', 0), 1)}
 json.dump(out, open(R + '/profiles/r%02d_pmc_traffic_%s.json' % (rnd, tag), 'w'), indent=1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense tools/profile_run_extra.sh's rocprofv3 outputs (gpurun_out/px_*) into profiles/r02_*: kernel statistics of the
+"""Condense tools/profile_run_extra.sh's rocprofv3 outputs (gpurun_out/px_*) into profiles/r03_*: kernel statistics of the
 two-fascicle + CSF/EAR classes and of the wide screening kernel, PMC counters per k2x launch class."""
 import collections, csv, glob, json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ for tag in ("k2x", "wide"):
     f = newest(R + '/gpurun_out/px_stats_%s/runc/*_kernel_stats.csv' % tag)
     if f:
         rows = list(csv.reader(open(f)))
-        with open(R + '/profiles/r02_kernel_stats_%s.csv' % tag, 'w') as o:
+        with open(R + '/profiles/r03_kernel_stats_%s.csv' % tag, 'w') as o:
             w = csv.writer(o)
             for r in rows[:9]:
                 r = list(r); r[0] = r[0][:110]
@@ -26,17 +26,19 @@ for d in glob.glob(R + '/gpurun_out/px_pmc_k2x_*/runc'):
     # group dispatches: 3 calls x ceil(10000/2048)=5 launches, then 3 x 2, then 3 x 2 (dispatch ids ascending)
     ids = sorted(set(int(r['Dispatch_Id']) for r in rows))
     cls_of = {}
-    plan = [("csf", 15), ("ear", 6), ("csf_ear", 6)]
-    q = 0
-    for name, n in plan:
-        for i in ids[q:q + n]:
-            cls_of[i] = name
-        q += n
+    # the two classes with EAR columns run 3 calls x 2 launches of 2 048 voxels each, at the end; whatever comes before them is
+    # the CSF class (screening pipeline: list-mode launches per 32 768 voxels + the hand-back launches)
+    for i in ids[-6:]:
+        cls_of[i] = "csf_ear"
+    for i in ids[-12:-6]:
+        cls_of[i] = "ear"
+    for i in ids[:-12]:
+        cls_of[i] = "csf"
     for r in rows:
         c = cls_of.get(int(r['Dispatch_Id']))
         if c:
             res[c][r['Counter_Name']] += float(r['Counter_Value'])
-out = {"round": 2, "command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/dev_time_configs.py (MFX_DEV_K2X_ONLY=1 MFX_DEV_MIX=1), one pass per counter group",
+out = {"round": 3, "command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/dev_time_configs.py (MFX_DEV_K2X_ONLY=1 MFX_DEV_MIX=1), one pass per counter group",
        "kernel": "mfx_fit_k2x_kernel<50,false,8,2>", "classes": {}}
 vox = {"csf": 3 * 10000, "ear": 3 * 4000, "csf_ear": 3 * 4000}
 for c, cnt in res.items():
@@ -49,10 +51,17 @@ for c, cnt in res.items():
                          "cu_cycles_per_voxel": cyc * 256 / V if V else None,
                          "mfma_busy_cycles_per_inst": cnt.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(cnt.get('SQ_INSTS_MFMA', 1), 1),
                          "mfma_pipe_utilisation": (cnt.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cyc) if cyc else None,
-                         "hbm_bytes_per_voxel_FETCHx2_plus_WRITE": (2 * cnt.get('FETCH_SIZE', 0) + cnt.get('WRITE_SIZE', 0)) * 1024.0 / V}
-json.dump(out, open(R + '/profiles/r02_pmc_k2x.json', 'w'), indent=1)
+                         "hbm_bytes_per_voxel_FETCHx2_plus_WRITE": (2 * cnt.get('FETCH_SIZE', 0) + cnt.get('WRITE_SIZE', 0)) * 1024.0 / V,
+                         "issue_utilisation": ((4.0 * cnt.get('SQ_INSTS_VALU', 0) + 8.0 * cnt.get('SQ_INSTS_MFMA', 0)) / (4.0 * cyc * 256)) if cyc else None}
+# what bench.py quotes for config 4 (the csf_ear class), at the top level; issue_utilisation = (4 VALU + 8 MFMA wave-instructions)
+# / (4 SIMDs x CU-cycles): the share of vector-issue slots in use, a lower bound (FP64 instructions take more than 4 cycles)
+c4 = out["classes"].get("csf_ear", {})
+out["issue_utilisation"] = c4.get("issue_utilisation")
+out["mfma_pipe_utilisation"] = c4.get("mfma_pipe_utilisation")
+out["hbm_bytes_per_voxel"] = c4.get("hbm_bytes_per_voxel_FETCHx2_plus_WRITE")
+json.dump(out, open(R + '/profiles/r03_pmc_k2x.json', 'w'), indent=1)
 print(json.dumps({c: {k: v for k, v in d.items() if k != "counters"} for c, d in out["classes"].items()}, indent=1))
 for tag in ("k2x", "wide"):
     src = R + '/gpurun_out/px_stats_%s.txt' % tag
     if os.path.exists(src):
-        open(R + '/profiles/r02_timing_%s.txt' % tag, 'w').write("".join(l for l in open(src) if 'amdgpu.ids' not in l))
+        open(R + '/profiles/r03_timing_%s.txt' % tag, 'w').write("".join(l for l in open(src) if 'amdgpu.ids' not in l))
