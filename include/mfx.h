@@ -116,7 +116,17 @@ int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const ui
 int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K, const uint8_t* csf,
                        const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
                        const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out);
-/* mfx_fit_batch / mfx_fit_batch_rows keep their pinned staging buffers and device buffers (signals, directions,
+/* Same, for a volume kept the way a NIfTI-1 file stores it (what nib.load(data) maps before get_fdata(), mf.py:623-626):
+ * vol is [M][nvox] scalars of NIfTI data type vol_dtype (2 u8, 4 i16, 8 i32, 16 f32, 64 f64, 256 i8, 512 u16, 768 u32;
+ * native byte order), one 3-D image per measurement; voxel v's signal is element vox[v] (0 <= vox[v] < nvox) of every
+ * image.  The volume is uploaded as it is; the reference's get_fdata()[mask > 0] (mf.py:644: conversion to float64,
+ * `x * scl_slope + scl_inter` when the header asks for it - scl_slope 0 means unscaled -, ROI gather) runs on the
+ * device with the same two roundings.                                                                          */
+int mfx_fit_batch_volume(const mfx_plan* p, const void* vol, int vol_dtype, double scl_slope, double scl_inter,
+                         int64_t nvox, const int64_t* vox, const int32_t* K, const uint8_t* csf, const uint8_t* ear,
+                         const double* peaks, int maxfasc, int csf_on, int ear_on, const double* sig_csf,
+                         const double* sig_ear, int E, int64_t V, double* params_out);
+/* mfx_fit_batch / mfx_fit_batch_rows / mfx_fit_batch_volume keep their pinned staging buffers and device buffers (signals, directions,
  * parameters) in the calling thread's state between calls and only ever grow them, so that a volume fitted slab by
  * slab (the reference's loop, mf.py:976-1032) pays no allocation per call; every entry point's scratch memory lives
  * in arenas the calling thread keeps per stream.  This returns all of it (after draining the thread's streams and

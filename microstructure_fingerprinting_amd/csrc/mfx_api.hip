@@ -946,7 +946,7 @@ extern "C" int mfx_fit_batch_dev(const mfx_plan* p, const double* d_Y, const dou
 static void pipe_release(MfxThread& T) {
   for (int q = 0; q < 2; ++q) { if (T.stage[q]) (void)hipHostFree(T.stage[q]); T.stage[q] = nullptr; }
   T.stage_bytes = 0;
-  for (int q = 0; q < 4; ++q) { if (T.pool[q]) (void)hipFree(T.pool[q]); T.pool[q] = nullptr; T.pool_bytes[q] = 0; }
+  for (int q = 0; q < 6; ++q) { if (T.pool[q]) (void)hipFree(T.pool[q]); T.pool[q] = nullptr; T.pool_bytes[q] = 0; }
 }
 
 static int pipe_setup(int device, size_t want_bytes) {
@@ -1014,11 +1014,81 @@ struct PoolPtr {     // borrowed pointer into the thread's buffer pool
 };
 }  // namespace
 
-extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K,
-                                  const uint8_t* csf, const uint8_t* ear, const double* peaks, int maxfasc, int csf_on,
-                                  int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
-                                  double* params_out) {
-  if (!p || !Y || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
+// ---- a volume kept the way a NIfTI file stores it: one 3-D image per measurement, [M][nvox] scalars of the file's
+// data type.  The volume goes to the device as it is (slices through the pinned staging buffers) and the reference's
+// `get_fdata()[mask > 0]` (mf.py:623-657: conversion to float64, scaling, ROI gather) happens there
+template <class S>
+__global__ __launch_bounds__(256) void mfx_volume_gather_kernel(const S* __restrict__ vol, long long nvox,
+                                                                const long long* __restrict__ vox, int V, int M,
+                                                                double slope, double inter, int scaled,
+                                                                double* __restrict__ Y) {
+  __shared__ double s[64][65];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int v0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const long long src = (v0 + lane < V) ? vox[v0 + lane] : -1;
+  for (int r = w; r < 64; r += 4) {          // lane = voxel: one image per row of the tile
+    double x = 0.0;
+    if (src >= 0 && m0 + r < M) {
+      x = (double)vol[(size_t)(m0 + r) * (size_t)nvox + (size_t)src];
+      if (scaled) x = __dadd_rn(__dmul_rn(x, slope), inter);      // two roundings, as NumPy's data * slope + inter
+    }
+    s[r][lane] = x;
+  }
+  __syncthreads();
+  for (int r = w; r < 64; r += 4)            // lane = measurement: one voxel's signal per row
+    if (v0 + r < V && m0 + lane < M) Y[(size_t)(v0 + r) * M + m0 + lane] = s[lane][r];
+}
+
+static size_t volume_elem_bytes(int code) {   // NIfTI-1 datatype codes
+  switch (code) {
+    case 2: case 256: return 1;
+    case 4: case 512: return 2;
+    case 8: case 768: case 16: return 4;
+    case 64: return 8;
+    default: return 0;
+  }
+}
+
+namespace {
+struct HostSource {    // where the host-buffer voxel loop finds the signals
+  const double* Y = nullptr;          // row-major [.. x M] doubles; voxel v: row rows[v] (rows == NULL: v)
+  const int64_t* rows = nullptr;
+  const void* vol = nullptr;          // or a measurement-major volume [M][nvox] of NIfTI type `dtype`; voxel v: element vox[v] of every image
+  int dtype = 0;
+  double slope = 0.0, inter = 0.0;
+  int64_t nvox = 0;
+  const int64_t* vox = nullptr;
+};
+}  // namespace
+
+static int volume_gather_launch(const HostSource& src, const void* d_vol, const long long* d_vox, int V, int M, double* d_Y,
+                                hipStream_t st) {
+  const int scaled = (src.slope != 0.0 && !(src.slope == 1.0 && src.inter == 0.0) && std::isfinite(src.slope)) ? 1 : 0;
+  const dim3 grid((unsigned)((V + 63) / 64), (unsigned)((M + 63) / 64));
+#define MFX_VG(TYPE) hipLaunchKernelGGL(mfx_volume_gather_kernel<TYPE>, grid, dim3(256), 0, st, (const TYPE*)d_vol, (long long)src.nvox, d_vox, V, M, src.slope, src.inter, scaled, d_Y)
+  switch (src.dtype) {
+    case 2: MFX_VG(uint8_t); break;
+    case 256: MFX_VG(int8_t); break;
+    case 4: MFX_VG(int16_t); break;
+    case 512: MFX_VG(uint16_t); break;
+    case 8: MFX_VG(int32_t); break;
+    case 768: MFX_VG(uint32_t); break;
+    case 16: MFX_VG(float); break;
+    case 64: MFX_VG(double); break;
+    default: return fail(MFX_ERR_ARG, "unsupported volume data type %d", src.dtype);
+  }
+#undef MFX_VG
+  HIPCHK(hipGetLastError());
+  return MFX_OK;
+}
+
+static int fit_batch_host(const mfx_plan* p, const HostSource& src, const int32_t* K,
+                          const uint8_t* csf, const uint8_t* ear, const double* peaks, int maxfasc, int csf_on,
+                          int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
+                          double* params_out) {
+  const double* Y = src.Y;
+  const int64_t* rows = src.rows;
+  if (!p || (!Y && !src.vol) || !K || !params_out || V < 0) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
   if (maxfasc < 0 || maxfasc > 3) return fail(MFX_ERR_ARG, "maxfasc must be 0..3 (MFModel.fit itself allows 2: MAX_FASC, mf.py:467)");
   if (maxfasc > 0 && !peaks) return fail(MFX_ERR_ARG, "mfx_fit_batch: peaks is null but maxfasc = %d", maxfasc);
   if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large");
@@ -1036,7 +1106,7 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   static const int64_t chunk_mb = [] { const char* e = std::getenv("MFX_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return (int64_t)(v > 0 ? v : 128); }();
   const int64_t CH = std::max<int64_t>(1024, std::min<int64_t>(V, (chunk_mb << 20) / ((int64_t)M * 8)));
   std::vector<int64_t> cstart;                   // first voxel of every chunk, then V
-  for (int64_t v0 = 0, n = std::max<int64_t>(1024, CH / 8); v0 < V; n = std::min<int64_t>(CH, 2 * n)) {
+  for (int64_t v0 = 0, n = src.vol ? V : std::max<int64_t>(1024, CH / 8); v0 < V; n = std::min<int64_t>(CH, 2 * n)) {   // (a volume is on the device before the first kernel: one chunk)
     cstart.push_back(v0);
     v0 += std::min<int64_t>(n, V - v0);
   }
@@ -1068,7 +1138,8 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
       for (int64_t v = cstart[c]; v < cstart[c + 1]; ++v) list[pos[(size_t)c * 16 + cls[(size_t)v]]++] = (int)v;
   }
   tr.mark("voxels binned");
-  if (int rc = pipe_setup(p->t->device, (size_t)CH * M * sizeof(double))) return rc;
+  const size_t vol_bytes = src.vol ? volume_elem_bytes(src.dtype) * (size_t)src.nvox * (size_t)M : 0;
+  if (int rc = pipe_setup(p->t->device, src.vol ? std::min<size_t>(vol_bytes, (size_t)64 << 20) : (size_t)CH * M * sizeof(double))) return rc;
   MfxThread& T = mfx_thread();
   PoolPtr dY, dpk, dpar, dlist;
   DevMem dsc, dse;
@@ -1076,6 +1147,11 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   if (int rc = pool_get(1, sizeof(double) * (size_t)V * 3 * std::max(maxfasc, 1), &dpk.p)) return rc;
   if (int rc = pool_get(2, sizeof(double) * (size_t)V * num_params, &dpar.p)) return rc;
   if (int rc = pool_get(3, sizeof(int) * (size_t)V, &dlist.p)) return rc;
+  PoolPtr dvol, dvox;
+  if (src.vol) {
+    if (int rc = pool_get(4, vol_bytes, &dvol.p)) return rc;
+    if (int rc = pool_get(5, sizeof(int64_t) * (size_t)V, &dvox.p)) return rc;
+  }
   tr.mark("buffers ready");
   // everything below is stream-ordered; any failure drains both streams before returning
   auto run = [&]() -> int {
@@ -1099,21 +1175,38 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
       if (int rc = xs[ce].build(M, ce >> 1, (ce & 1) ? E : 0, dsc.as<double>(), dse.as<double>(), T.s_comp)) return rc;
     }
     size_t off = 0;
+    if (src.vol) {   // the whole volume, slice by slice through the two staging buffers; then one gather on the device
+      HIPCHK(hipMemcpyAsync(dvox.p, src.vox, sizeof(int64_t) * (size_t)V, hipMemcpyHostToDevice, T.s_comp));
+      const size_t slice = T.stage_bytes;
+      int64_t q = 0;
+      for (size_t o = 0; o < vol_bytes; o += slice, ++q) {
+        const size_t nb = std::min(slice, vol_bytes - o);
+        if (q >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[q & 1]));
+        std::memcpy(T.stage[q & 1], (const char*)src.vol + o, nb);
+        HIPCHK(hipMemcpyAsync((char*)dvol.p + o, T.stage[q & 1], nb, hipMemcpyHostToDevice, T.s_copy));
+        HIPCHK(hipEventRecord(T.ev_h2d[q & 1], T.s_copy));
+      }
+      HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[(q + 1) & 1], 0));   // the last copy: everything before it on s_copy is done too
+      tr.mark("  volume staged");
+      if (int rc = volume_gather_launch(src, dvol.p, dvox.as<long long>(), (int)V, M, dY.as<double>(), T.s_comp)) return rc;
+    }
     for (int64_t c = 0; c < nch; ++c) {
       const int64_t v0 = cstart[c], nv = cstart[c + 1] - v0;
-      double* stg = (double*)T.stage[c & 1];
-      if (c >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[c & 1]));   // the copy that last used this staging buffer is done
-      tr.mark("  staging buffer free");
-      if (rows) {
-        for (int64_t v = 0; v < nv; ++v) std::memcpy(stg + (size_t)v * M, Y + (size_t)rows[v0 + v] * M, sizeof(double) * M);
-      } else {
-        std::memcpy(stg, Y + (size_t)v0 * M, sizeof(double) * (size_t)nv * M);
+      if (!src.vol) {
+        double* stg = (double*)T.stage[c & 1];
+        if (c >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[c & 1]));   // the copy that last used this staging buffer is done
+        tr.mark("  staging buffer free");
+        if (rows) {
+          for (int64_t v = 0; v < nv; ++v) std::memcpy(stg + (size_t)v * M, Y + (size_t)rows[v0 + v] * M, sizeof(double) * M);
+        } else {
+          std::memcpy(stg, Y + (size_t)v0 * M, sizeof(double) * (size_t)nv * M);
+        }
+        tr.mark("  chunk gathered");
+        HIPCHK(hipMemcpyAsync(dY.as<double>() + (size_t)v0 * M, stg, sizeof(double) * (size_t)nv * M, hipMemcpyHostToDevice, T.s_copy));
+        HIPCHK(hipEventRecord(T.ev_h2d[c & 1], T.s_copy));
+        HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[c & 1], 0));
+        tr.mark("  copy queued");
       }
-      tr.mark("  chunk gathered");
-      HIPCHK(hipMemcpyAsync(dY.as<double>() + (size_t)v0 * M, stg, sizeof(double) * (size_t)nv * M, hipMemcpyHostToDevice, T.s_copy));
-      HIPCHK(hipEventRecord(T.ev_h2d[c & 1], T.s_copy));
-      HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[c & 1], 0));
-      tr.mark("  copy queued");
       for (int q = 0; q < 16; ++q) {
         const int n = cnt[(size_t)c * 16 + q];
         if (!n) continue;
@@ -1134,6 +1227,35 @@ extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int6
   if (rc == MFX_OK && (e1 != hipSuccess || e2 != hipSuccess))
     rc = fail(MFX_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return rc;
+}
+
+extern "C" int mfx_fit_batch_rows(const mfx_plan* p, const double* Y, const int64_t* rows, const int32_t* K,
+                                  const uint8_t* csf, const uint8_t* ear, const double* peaks, int maxfasc, int csf_on,
+                                  int ear_on, const double* sig_csf, const double* sig_ear, int E, int64_t V,
+                                  double* params_out) {
+  if (!Y) return fail(MFX_ERR_ARG, "mfx_fit_batch: bad argument");
+  HostSource src;
+  src.Y = Y;
+  src.rows = rows;
+  return fit_batch_host(p, src, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf, sig_ear, E, V, params_out);
+}
+
+extern "C" int mfx_fit_batch_volume(const mfx_plan* p, const void* vol, int vol_dtype, double scl_slope, double scl_inter,
+                                    int64_t nvox, const int64_t* vox, const int32_t* K, const uint8_t* csf,
+                                    const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
+                                    const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {
+  if (!vol || !vox || nvox <= 0) return fail(MFX_ERR_ARG, "mfx_fit_batch_volume: bad argument");
+  if (!volume_elem_bytes(vol_dtype)) return fail(MFX_ERR_ARG, "mfx_fit_batch_volume: unsupported NIfTI data type %d", vol_dtype);
+  for (int64_t v = 0; v < V; ++v)
+    if (vox[v] < 0 || vox[v] >= nvox) return fail(MFX_ERR_ARG, "mfx_fit_batch_volume: voxel %lld: index %lld outside the volume", (long long)v, (long long)vox[v]);
+  HostSource src;
+  src.vol = vol;
+  src.dtype = vol_dtype;
+  src.slope = scl_slope;
+  src.inter = scl_inter;
+  src.nvox = nvox;
+  src.vox = vox;
+  return fit_batch_host(p, src, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf, sig_ear, E, V, params_out);
 }
 
 extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,

@@ -53,8 +53,8 @@ struct MfxThread {
   // device buffers of mfx_fit_batch (signals, directions, parameters, voxel lists): kept between calls and only ever
   // grown, so that a volume fitted slab by slab does not pay an allocation and a (synchronising) release per call;
   // mfx_thread_release() returns them
-  void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t pool_bytes[4] = {0, 0, 0, 0};
+  void* pool[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4], [5]: a volume in its file's layout and the ROI's indices into it
+  size_t pool_bytes[6] = {0, 0, 0, 0, 0, 0};
   // two internal streams of the voxel-by-voxel three-fascicle path (two voxels in flight: the launch gaps and the
   // tail of one voxel's kernels are covered by the other's), forked from and joined to the caller's stream by events
   // scratch arenas (mfx_scratch_alloc): one per (device, stream) this thread has launched on

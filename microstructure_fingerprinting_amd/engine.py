@@ -79,6 +79,66 @@ def num_params(maxfasc, csf_on, ear_on):
     return 1 + 2 * maxfasc + int(csf_on) + 2 * int(ear_on) + 2   # mf.py:381
 
 
+class FileOrderVolume(object):
+    """A 4-D data volume in the layout NIfTI files (and nibabel's arrays) have: ``array`` is Fortran-contiguous with
+    shape (..., M), i.e. one 3-D image per measurement, in one of the scalar types of ``NIFTI_CODES``; ``slope`` /
+    ``inter`` are the header's scaling (slope 0: none).  ``get_fdata()`` gives what nib.load(f).get_fdata() would."""
+    NIFTI_CODES = {'u1': 2, 'i2': 4, 'i4': 8, 'f4': 16, 'f8': 64, 'i1': 256, 'u2': 512, 'u4': 768}
+
+    def __init__(self, array, slope=0.0, inter=0.0):
+        self.array, self.slope, self.inter = array, float(slope), float(inter)
+        self.shape = array.shape
+
+    @staticmethod
+    def accepts(a):
+        return (isinstance(a, np.ndarray) and a.ndim >= 2 and a.flags.f_contiguous and not a.flags.c_contiguous
+                and a.dtype.isnative and a.dtype.str[1:] in FileOrderVolume.NIFTI_CODES)
+
+    @property
+    def scaled(self):
+        return self.slope != 0.0 and not (self.slope == 1.0 and self.inter == 0.0) and np.isfinite(self.slope)
+
+    def get_fdata(self):
+        d = self.array.astype(np.float64)
+        return d * self.slope + self.inter if self.scaled else d
+
+    def file_order_index(self, c_flat_index):
+        """Positions inside one 3-D image of the voxels with C-order flat indices ``c_flat_index`` of the image grid."""
+        grid = self.shape[:-1]
+        return np.ravel_multi_index(np.unravel_index(c_flat_index, grid), grid, order='F').astype(np.int64)
+
+
+def fit_batch_volume(plan, vol, vox, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0):
+    """mfx_fit_batch_volume: like ``fit_batch(plan, vol.get_fdata().reshape(-1, M, order='F')[vox], ...)`` with the
+    volume uploaded in its own layout and type and the conversion, scaling and ROI gather (mf.py:623-657) on the device."""
+    a = vol.array
+    M = a.shape[-1]
+    if M != plan.M:
+        raise ValueError("data has %d measurements, protocol has %d" % (M, plan.M))
+    nvox = int(np.prod(a.shape[:-1]))
+    vox = np.ascontiguousarray(vox, dtype=np.int64)
+    V = vox.shape[0]
+    if V and (vox.min() < 0 or vox.max() >= nvox):
+        raise ValueError("voxel indices out of range")
+    K = np.ascontiguousarray(K, dtype=np.int32)
+    if K.shape[0] != V:
+        raise ValueError("K should have one entry per voxel")
+    csf_a = np.ascontiguousarray(csf, dtype=np.uint8) if csf is not None else np.zeros(V, np.uint8)
+    ear_a = np.ascontiguousarray(ear, dtype=np.uint8) if ear is not None else np.zeros(V, np.uint8)
+    pk = L.f64c(peaks).reshape(V, -1) if maxfasc > 0 else np.zeros((V, 3))
+    if maxfasc > 0 and pk.shape[1] != 3 * maxfasc:
+        raise ValueError("peaks should have %d columns" % (3 * maxfasc))
+    out = np.zeros((V, num_params(maxfasc, csf_on, ear_on)))
+    sc = L.f64c(sig_csf) if sig_csf is not None else None
+    se = L.f64c(sig_ear) if sig_ear is not None else None
+    L.check(L.lib().mfx_fit_batch_volume(plan.handle(), a.ctypes.data, FileOrderVolume.NIFTI_CODES[a.dtype.str[1:]],
+                                         vol.slope, vol.inter, nvox, L.lptr(vox), L.iptr(K), L.bptr(csf_a), L.bptr(ear_a),
+                                         L.dptr(pk), int(maxfasc), int(csf_on), int(ear_on),
+                                         L.dptr(sc) if sc is not None else None, L.dptr(se) if se is not None else None,
+                                         int(E), V, L.dptr(out)))
+    return out
+
+
 def fit_batch(plan, Y, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0, rows=None):
     """Host-buffer voxel loop (mfx_fit_batch_rows): returns params_in_mask [V x num_params] (mf.py:1018-1028).
 

@@ -106,6 +106,7 @@ def cleanup_2fascicles(frac1, frac2, peakmode, mu1, mu2, mask, frac12=None):
 class MFModel():
     r"""Microstructure Fingerprinting model (ref:464-1051)."""
     MAX_FASC = 2          # ref:467
+    SHARD_DEVICES = None  # parallel=True: device of every shard; None: each visible GPU once (a device may be named twice)
     MAX_PROG_LINES = 100  # ref:468 (kept for API compatibility; progress is per batch here)
     DFT_DISP_ITVL = 5     # ref:469
 
@@ -134,7 +135,22 @@ class MFModel():
         t0 = time.time()
         if isinstance(data, str) and VRB >= 2:
             print("Loading data from file %s..." % data)
-        data_arr, aff = _load_volume(data)
+        # a volume in file order (a NIfTI file, or nibabel's Fortran-ordered array) stays as it is: conversion to
+        # float64, the header's scaling and the ROI gather (ref:623-657) run on the device (mfx_fit_batch_volume)
+        vol = None
+        if isinstance(data, str):
+            raw, slope, inter, aff = nifti.load_raw(data)
+            if engine.FileOrderVolume.accepts(raw):
+                vol = engine.FileOrderVolume(raw, slope, inter)
+                data_arr = raw
+            else:
+                data_arr = np.array(raw, dtype=np.float64)
+                if slope != 0.0 and not (slope == 1.0 and inter == 0.0) and np.isfinite(slope):
+                    data_arr = data_arr * slope + inter
+        else:
+            data_arr, aff = data, None
+            if engine.FileOrderVolume.accepts(data_arr):
+                vol = engine.FileOrderVolume(data_arr)
         nii_affine = aff
         if isinstance(data, str) and VRB >= 2:
             print("Data loaded in %g s." % (time.time() - t0))
@@ -273,7 +289,10 @@ class MFModel():
         # ---- the voxel loop, batched on the device (replaces ref:976-1032)
         # ROI order == np.where(mask > 0).  A float64 C-contiguous volume is handed over as it is with the ROI's row
         # numbers: the library gathers the rows while it stages the upload (the reference's data[mask > 0], ref:644)
-        if isinstance(data_arr, np.ndarray) and data_arr.dtype == np.float64 and data_arr.flags.c_contiguous:
+        if vol is not None:
+            Y = vol
+            rows = vol.file_order_index(roi_index)
+        elif isinstance(data_arr, np.ndarray) and data_arr.dtype == np.float64 and data_arr.flags.c_contiguous:
             Y = data_arr.reshape(-1, num_seq)
             rows = roi_index.astype(np.int64, copy=False)
         else:
@@ -283,12 +302,13 @@ class MFModel():
         if VRB >= 2:
             print("Starting estimation in %d voxel(s) on the GPU%s." % (ROI_size, "s (sharded)" if parallel else ""))
         args = (numfasc_roi, csf_mask, ear_mask, peaks_roi, maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear)
-        ndev = L.lib().mfx_device_count()
-        if parallel and ndev > 1 and ROI_size >= 2 * ndev:
-            params_in_mask = self._fit_sharded(pgse_scheme, Y, rows, args, ndev)
+        devs = list(range(L.lib().mfx_device_count())) if self.SHARD_DEVICES is None else list(self.SHARD_DEVICES)
+        if parallel and len(devs) > 1 and ROI_size >= 2 * len(devs):
+            params_in_mask = self._fit_sharded(pgse_scheme, Y, rows, args, devs)
         else:
             plan = self.ms_interpolator.plan_for(pgse_scheme)
-            params_in_mask = engine.fit_batch(plan, Y, *args, rows=rows)
+            params_in_mask = (engine.fit_batch_volume(plan, Y, rows, *args) if vol is not None
+                              else engine.fit_batch(plan, Y, *args, rows=rows))
         if VRB >= 2:
             print("Estimation performed in %g second(s)." % (time.time() - st))
         fitinfo = {'maxfasc': maxfasc, 'csf_on': csf_on, 'ear_on': ear_on, 'affine': nii_affine, 'mask': mask_arr,
@@ -314,13 +334,14 @@ class MFModel():
                              % (name, " ".join("%d" % x for x in img_shape), " ".join("%d" % x for x in m.shape)))
         return (m[roi] > 0), aff
 
-    def _fit_sharded(self, pgse_scheme, Y, rows, args, ndev):
+    def _fit_sharded(self, pgse_scheme, Y, rows, args, devs):
         """parallel=True: one host thread per GPU (ctypes releases the GIL), each device with its own copy of the
         tables.  The voxels of every class (numfasc, CSF, EAR: their cost differs by up to 40x) are dealt round-robin
         over the devices so that each gets the same mix (reference: mp.Pool over voxels, ref:978-1009).
         (Multi-process / multi-node runs use dist.py.)"""
         numfasc_roi, csf_mask, ear_mask, peaks_roi, maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear = args
         V = numfasc_roi.shape[0]
+        ndev = len(devs)
         out = [None] * ndev
         idx = [mdist.balanced_shard_indices(numfasc_roi, csf_mask, ear_mask, d, ndev) for d in range(ndev)]
         errs = []
@@ -329,10 +350,13 @@ class MFModel():
             try:
                 ix = idx[d]
                 ms = mfu.MultiShellInterpolator(self.ms_interpolator['scheme_DeldelTE'], self.ms_interpolator['Gms_un'],
-                                                self.ms_interpolator['interpolators'], device=d)
-                out[d] = engine.fit_batch(ms.plan_for(pgse_scheme), Y, numfasc_roi[ix], csf_mask[ix], ear_mask[ix],
-                                          peaks_roi[ix], maxfasc, csf_on, ear_on, sig_csf, sig_ear, num_ear,
-                                          rows=(ix if rows is None else rows[ix]))
+                                                self.ms_interpolator['interpolators'], device=devs[d])
+                part = (numfasc_roi[ix], csf_mask[ix], ear_mask[ix], peaks_roi[ix], maxfasc, csf_on, ear_on, sig_csf,
+                        sig_ear, num_ear)
+                if isinstance(Y, engine.FileOrderVolume):
+                    out[d] = engine.fit_batch_volume(ms.plan_for(pgse_scheme), Y, rows[ix], *part)
+                else:
+                    out[d] = engine.fit_batch(ms.plan_for(pgse_scheme), Y, *part, rows=(ix if rows is None else rows[ix]))
             except Exception as e:   # re-raised below, like pool.get() (ref:1006-1008)
                 errs.append(e)
         th = [threading.Thread(target=work, args=(d,)) for d in range(ndev)]

@@ -19,17 +19,8 @@ def _open(path, mode):
     return gzip.open(path, mode) if str(path).endswith(".gz") else open(path, mode)
 
 
-def load(path):
-    """Return ``(data as float64 ndarray, 4x4 affine)`` like ``nib.load(p).get_fdata()`` / ``.affine``."""
-    try:
-        import nibabel as nib
-        img = nib.load(path)
-        return img.get_fdata(), img.affine
-    except ImportError:
-        pass
-    with _open(path, "rb") as f:
-        raw = f.read()
-    hdr = raw[:348]
+def _header(hdr, path):
+    """Parsed NIfTI-1 header fields needed here: (dtype, shape, vox_offset, slope, inter, affine)."""
     endian = "<"
     if struct.unpack("<i", hdr[0:4])[0] != 348:
         endian = ">"
@@ -47,10 +38,6 @@ def load(path):
         raise ValueError("%s: unsupported NIfTI datatype %d" % (path, datatype))
     shape = tuple(int(d) for d in dim[1:1 + dim[0]])
     dt = np.dtype(_DTYPES[datatype]).newbyteorder(endian)
-    n = int(np.prod(shape))
-    data = np.frombuffer(raw, dtype=dt, count=n, offset=vox_offset).reshape(shape, order="F").astype(np.float64)
-    if slope not in (0.0,) and not (slope == 1.0 and inter == 0.0) and np.isfinite(slope):
-        data = data * slope + inter
     aff = np.eye(4)
     if sform_code > 0:
         aff[0, :] = struct.unpack(endian + "4f", hdr[280:296])
@@ -68,6 +55,48 @@ def load(path):
         aff[:3, 3] = [qx, qy, qz]
     else:
         aff[:3, :3] = np.diag(pixdim[1:4])
+    return dt, shape, vox_offset, float(slope), float(inter), aff
+
+
+def _scaled(slope, inter):
+    return slope != 0.0 and not (slope == 1.0 and inter == 0.0) and np.isfinite(slope)
+
+
+def load_raw(path):
+    """``(array, slope, inter, affine)``: the file's own scalars, Fortran-ordered in the file's shape (a read-only
+    memory map for an uncompressed file), with the header's scaling left to the caller: what nibabel's
+    ``img.dataobj.get_unscaled()``, ``.slope``, ``.inter`` and ``img.affine`` are."""
+    try:
+        import nibabel as nib
+        img = nib.load(path)
+        return np.asanyarray(img.dataobj.get_unscaled()), float(img.dataobj.slope), float(img.dataobj.inter), img.affine
+    except ImportError:
+        pass
+    if str(path).endswith(".gz"):
+        with _open(path, "rb") as f:
+            raw = f.read()
+        dt, shape, off, slope, inter, aff = _header(raw[:348], path)
+        data = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape)), offset=off).reshape(shape, order="F")
+    else:
+        with open(path, "rb") as f:
+            hdr = f.read(348)
+        dt, shape, off, slope, inter, aff = _header(hdr, path)
+        data = np.memmap(path, dtype=dt, mode="r", offset=off, shape=shape, order="F")
+    return data, slope, inter, aff
+
+
+def load(path):
+    """Return ``(data as float64 ndarray, 4x4 affine)`` like ``nib.load(p).get_fdata()`` / ``.affine``."""
+    try:
+        import nibabel as nib
+        img = nib.load(path)
+        return img.get_fdata(), img.affine
+    except ImportError:
+        pass
+    raw, slope, inter, aff = load_raw(path)
+    data = np.array(raw, dtype=np.float64)
+    if _scaled(slope, inter):
+        data = data * slope + inter
     return data, aff
 
 
@@ -101,5 +130,9 @@ def save(data, affine, path):
     struct.pack_into("<4f", hdr, 296, *aff[1])
     struct.pack_into("<4f", hdr, 312, *aff[2])
     hdr[344:348] = b"n+1\0"
-    with _open(path, "wb") as f:
-        f.write(bytes(hdr) + b"\0\0\0\0" + np.asfortranarray(arr).astype("<" + key).tobytes(order="F"))
+    img = np.asfortranarray(arr)
+    if img.dtype.str[0] == ">":
+        img = img.astype("<" + key)
+    with _open(path, "wb") as f:     # the image goes out in place: the transpose of a Fortran-ordered array is C-contiguous
+        f.write(bytes(hdr) + b"\0\0\0\0")
+        f.write(img.T.data if img.ndim else img.tobytes())

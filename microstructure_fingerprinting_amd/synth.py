@@ -70,3 +70,62 @@ def make_voxels(rng, V, K, rotate, N, M0=500.0, snr=30.0):
         Y = (0 if Y is None else Y) + M0 * nu[:, k:k + 1] * col
     Y = Y + rng.normal(0, M0 / snr, Y.shape)
     return peaks, Y, atoms, nu
+
+
+def make_phantom(model, grid, rng, k_frac=(0.1, 0.3, 0.6), p_csf=0.3, p_ear=0.1, M0=500.0, snr=30.0, device=0):
+    """A brain-sized test volume for MFModel.fit: ellipsoidal mask inside ``grid``; per ROI voxel a number of fascicles
+    drawn with probabilities ``k_frac`` (0, 1, 2), CSF / EAR flags with probabilities p_csf / p_ear, random directions,
+    y = M0 * sum nu_c * component_c + noise.  Signals are generated on the device (rotated atoms through the model's
+    plan) and returned as float32 in file order (Fortran-contiguous [grid x M], the layout of a NIfTI file).
+    Returns dict(data, mask, numfasc, peaks, csf_mask, ear_mask) of arrays over ``grid``."""
+    import torch
+    from . import engine
+    from . import mf_utils as mfu
+    sch = np.ascontiguousarray(model.dic['sch_mat'], dtype=np.float64)
+    plan = model.ms_interpolator.plan_for(sch)
+    M, N = sch.shape[0], int(model.dic['num_atom'])
+    ax = [(np.arange(n) + 0.5) / n * 2 - 1 for n in grid]
+    r2 = ax[0][:, None, None] ** 2 + ax[1][None, :, None] ** 2 + ax[2][None, None, :] ** 2
+    mask = (r2 <= 1.0).astype(np.float64)
+    roi = np.flatnonzero(mask.reshape(-1))
+    V = roi.shape[0]
+    K = rng.choice(3, V, p=np.asarray(k_frac) / np.sum(k_frac))
+    csf = rng.random(V) < p_csf
+    ear = rng.random(V) < p_ear
+    pk = np.concatenate([unit_vectors(rng, V), unit_vectors(rng, V)], axis=1)
+    pk[K < 2, 3:] = 0
+    pk[K < 1, :3] = 0
+    nu = rng.dirichlet(np.ones(4), V) * np.stack([K >= 1, K >= 2, csf, ear], axis=1)
+    nu /= np.maximum(nu.sum(axis=1, keepdims=True), 1e-300)
+    gam = mfu.get_gyromagnetic_ratio('H')
+    b = (gam * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / model.dic['T2_csf']) * np.exp(-b * model.dic['DIFF_csf'])
+    D_ear = np.atleast_1d(model.dic['DIFF_ear'])
+    sig_ear = np.exp(-sch[:, 6] / model.dic['T2_ear'])[:, None] * np.exp(-b[:, None] * D_ear[None, :])
+    dev = torch.device("cuda", device)
+    Y = torch.zeros((V, M), dtype=torch.float64, device=dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    safe = np.where(np.any(pk[:, :3], axis=1, keepdims=True), pk[:, :3], [0, 0, 1.0])
+    safe2 = np.where(np.any(pk[:, 3:], axis=1, keepdims=True), pk[:, 3:], [0, 0, 1.0])
+    for k, d in enumerate((safe, safe2)):
+        col = engine.rotate_columns_dev(plan, t(d), t(rng.integers(0, N, V).astype(np.int32)))
+        Y += t(nu[:, k:k + 1]) * col
+    Y += t(nu[:, 2:3]) * t(sig_csf)[None, :]
+    Y += t(nu[:, 3:4]) * t(sig_ear.T.copy())[t(rng.integers(0, D_ear.shape[0], V))]
+    Y = M0 * Y + (M0 / snr) * torch.randn((V, M), dtype=torch.float64, device=dev,
+                                          generator=torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 31))))
+    nvox = int(np.prod(grid))
+    fidx = np.ravel_multi_index(np.unravel_index(roi, grid), grid, order='F')
+    planes = torch.zeros((M, nvox), dtype=torch.float32, device=dev)
+    planes[:, t(fidx)] = Y.T.to(torch.float32)
+    data = planes.cpu().numpy().reshape((M,) + tuple(grid)[::-1]).T          # (grid x M), Fortran-contiguous
+    del planes, Y
+    vol = lambda vals, extra=(): _scatter(vals, roi, grid, extra)
+    return {"data": data, "mask": mask, "numfasc": vol(K.astype(np.float64)), "peaks": vol(pk, (6,)),
+            "csf_mask": vol(csf.astype(np.float64)), "ear_mask": vol(ear.astype(np.float64))}
+
+
+def _scatter(vals, roi, grid, extra=()):
+    out = np.zeros((int(np.prod(grid)),) + tuple(extra))
+    out[roi] = vals
+    return out.reshape(tuple(grid) + tuple(extra))
