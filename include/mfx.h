@@ -204,6 +204,10 @@ int mfx_debug_last_counter(int which);
 /* Diagnostic: candidate-list entries per voxel of the batched three-fascicle path (fit_k3.hip; 0: the built-in 4 M).  A voxel
  * whose list overflows is redone by the voxel-by-voxel path, gated on the device; tests lower the cap to force that. */
 void mfx_debug_set_k3_cap(int cap);
+/* Diagnostic: 1 sends every voxel class (0, 1 or 2 fascicles, with or without CSF / EAR) of mfx_fit_batch* voxel by voxel
+ * through the explicit-dictionary solver, the path shapes beyond the fused kernels' limits take by themselves (dictionaries
+ * or protocols too large for the LDS, more than 16 CSF+EAR columns); tests use it to check that path on small shapes. */
+void mfx_debug_set_force_generic(int enabled);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: 1 routes two-fascicle voxels of protocols with 129..256 measurements to the wide (one wave per SIMD)

@@ -221,6 +221,7 @@ extern "C" void mfx_debug_set_stamps(void* dev_ptr) { mfx_thread().stamps = (uns
 extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc < 0 || maxc > MFX_MAXC) ? MFX_MAXC : maxc; }
 extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }
 extern "C" void mfx_debug_set_k3_cap(int cap) { mfx_thread().k3_cap = cap > 0 ? cap : 0; }
+extern "C" void mfx_debug_set_force_generic(int enabled) { mfx_thread().force_generic = enabled ? 1 : 0; }
 extern "C" void mfx_debug_set_k2s_images(int nb) { mfx_thread().k2s_nb = (nb == 2) ? 2 : 0; }
 extern "C" void mfx_debug_set_k2s_cap(int cap) {
   int c = 4;
@@ -589,7 +590,6 @@ struct ExtrasHost {
     st = stream;
     d.NX = NX; d.has_csf = has_csf; d.E = E; d.x = nullptr; d.Gxx = nullptr;
     if (NX == 0) return MFX_OK;
-    if (NX > MFX_NXMAX) return fail(MFX_ERR_UNSUPPORTED, "at most %d CSF+EAR columns are supported (got %d)", MFX_NXMAX, NX);
     if (has_csf && !d_sig_csf) return fail(MFX_ERR_ARG, "sig_csf missing");
     if (E && !d_sig_ear) return fail(MFX_ERR_ARG, "sig_ear missing");
     HIPCHK(mfx_scratch_alloc(&dx, sizeof(double) * (size_t)M * NX, st));
@@ -610,6 +610,7 @@ static int launch_small(const FitSmallArgs& a, int nvox, hipStream_t st) {
   const int M = a.P.M;
   const size_t lds = sizeof(double) * (3 * (size_t)M + MFX_NXMAX + 8 + MFX_SWG + 3 * MFX_SWG + (size_t)a.T.N + MFX_SATOMS * ((size_t)M + 32) + (size_t)M * a.X.NX) + sizeof(long) * MFX_SWG +
                      sizeof(int) * (2 * (size_t)M + MFX_SLIST + 1);
+  if (a.X.NX > MFX_NXMAX) return fail(MFX_ERR_UNSUPPORTED, "one-fascicle kernel: at most %d CSF+EAR columns (got %d)", MFX_NXMAX, a.X.NX);
   if (lds > 160 * 1024) return fail(MFX_ERR_UNSUPPORTED, "too many measurements (%d) or atoms (%d) for the one-fascicle kernel", M, a.T.N);
   if (int rc = mfx_prof_begin(st)) return rc;
   if (a.P.any_bracket) {
@@ -632,12 +633,31 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
                           int maxfasc, int csf_on, int ear_on, double* d_params, hipStream_t st);
 
 // h_list: host copy of d_list (null with d_list == null: the identity)
+static int fit_class_fused(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
+                           const int* h_list, int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc,
+                           int csf_on, int ear_on, double* d_params, hipStream_t st);
 static int fit_class_dev(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
                          const int* h_list, int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc,
                          int csf_on, int ear_on, double* d_params, hipStream_t st) {
-  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   if (nvox == 0) return MFX_OK;
   if (K + has_csf + has_ear == 0) return MFX_OK;  // mf.py:387-388: rows stay zero
+  MfxThread& T = mfx_thread();
+  int rc = T.force_generic ? MFX_ERR_UNSUPPORTED
+                           : fit_class_fused(p, d_Y, d_peaks, peaks_ld, d_list, h_list, nvox, K, has_csf, has_ear, X, maxfasc, csf_on, ear_on, d_params, st);
+  // a shape outside the fused kernels' limits (dictionary or protocol too large for the LDS, more CSF+EAR columns than
+  // their register arrays hold; they refuse before anything is enqueued): voxel by voxel through the explicit-dictionary
+  // solver, which has no such limits - slower by orders of magnitude, same results
+  if (rc == MFX_ERR_UNSUPPORTED && K <= 2) {
+    if (!h_list && d_list) return fail(MFX_ERR_ARG, "internal: class list without its host copy");
+    rc = fit_class_generic(p, d_Y, d_peaks, peaks_ld, h_list, nvox, K, X, maxfasc, csf_on, ear_on, d_params, st);
+  }
+  return rc;
+}
+
+static int fit_class_fused(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* d_list,
+                           const int* h_list, int nvox, int K, int has_csf, int has_ear, const ExtrasHost& X, int maxfasc,
+                           int csf_on, int ear_on, double* d_params, hipStream_t st) {
+  const int num_params = 1 + 2 * maxfasc + csf_on + 2 * ear_on + 2;
   if (K <= 1) {
     FitSmallArgs a{};
     a.T = p->t->d; a.P = p->d; a.X = X.d;
@@ -892,9 +912,10 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   for (int q = 0; q < nvox && rc_loop == MFX_OK; ++q) {
     const int l = q % nl;
     const long v = h_list ? h_list[q] : q;
-    dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, K);
-    hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, ls[l], p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
-                       sets[l]->dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
+    dim3 grid((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, std::max(K, 1));
+    if (K > 0)
+      hipLaunchKernelGGL(mfx_rotate_kernel, grid, dim3(MFX_ROT_WG), 0, ls[l], p->t->d, p->d, d_peaks + (size_t)v * peaks_ld, 0,
+                         sets[l]->dA.as<double>(), (long)N, Ntot);   // (an explicit plan normalises the direction inside mfx_row_desc)
     av[l].y = d_Y + (size_t)v * M;
     rc_loop = launch_solver(av[l], k3 ? &kbv[l] : nullptr, ls[l]);
     if (rc_loop != MFX_OK) break;

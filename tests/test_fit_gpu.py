@@ -699,3 +699,101 @@ def test_k2_long_protocols(dirs, c, bracket):
     got = engine.fit_batch(ms.plan_for(sch), Y, Kv, cm, z, peaks, 2, bool(c), False, sig_csf if c else None, None, 0)
     assert np.array_equal(got[:, 3:5], ref[:, 3:5])
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-9)
+
+
+def _extras(sch, E):
+    from oracle import oracle as orc
+    b = (orc.GAMMA_H * sch[:, 3] * sch[:, 5]) ** 2 * (sch[:, 4] - sch[:, 5] / 3)
+    sig_csf = np.exp(-sch[:, 6] / 2.0) * np.exp(-b * 3e-9)
+    sig_ear = np.stack([np.exp(-sch[:, 6] / 0.08) * np.exp(-b * x) for x in np.linspace(0.2e-9, 1.2e-9, E)], axis=1)
+    return sig_csf, sig_ear
+
+
+def _mixed_voxels(rng, ms, sch, T, N, V, sig_csf, sig_ear, kmax=2):
+    from microstructure_fingerprinting_amd import synth
+    from oracle import oracle as orc
+    Kv = rng.integers(0, kmax + 1, V)
+    cm = rng.random(V) < 0.5
+    em = rng.random(V) < 0.5
+    peaks = np.concatenate([synth.unit_vectors(rng, V), synth.unit_vectors(rng, V)], axis=1)
+    Y = rng.normal(0, 12.0, (V, sch.shape[0]))
+    for v in range(V):
+        comps = [orc.interp(sch, peaks[v, 3 * k:3 * k + 3], T)[:, rng.integers(0, N)] for k in range(Kv[v])]
+        if cm[v]:
+            comps.append(sig_csf)
+        if em[v]:
+            comps.append(sig_ear[:, rng.integers(0, sig_ear.shape[1])])
+        if comps:
+            Y[v] += 400 * np.stack(comps, 1) @ rng.dirichlet(np.ones(len(comps)))
+    return Kv, cm, em, peaks, Y
+
+
+def _mask_inactive_ids(got, ref):
+    got, ref = got.copy(), ref.copy()
+    for col_nu, col_id in ((1, 3), (2, 4), (6, 7)):
+        off = ref[:, col_nu] <= 1e-9
+        got[off, col_id] = 0; ref[off, col_id] = 0
+    return got, ref
+
+
+def test_out_of_limits_fallback_forced_on_every_class():
+    """The path shapes beyond the fused kernels' limits take (voxel by voxel through the explicit-dictionary solver),
+    forced on a small mixed ROI: every class K in {0, 1, 2} x CSF x EAR equals the fused kernels and the CPU restatement."""
+    from microstructure_fingerprinting_amd import engine, synth, _lib as L
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng(77)
+    c = synth.config("C1")
+    sch = synth.make_scheme(rng, c["n_b0"], c["shells_b"], c["dirs"])
+    N, E, V = 40, 4, 72
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    sig_csf, sig_ear = _extras(sch, E)
+    Kv, cm, em, peaks, Y = _mixed_voxels(rng, ms, sch, T, N, V, sig_csf, sig_ear)
+    assert len(set(zip(Kv, cm, em))) == 12
+    plan = ms.plan_for(sch)
+    fused = engine.fit_batch(plan, Y, Kv, cm, em, peaks, 2, True, True, sig_csf, sig_ear, E)
+    L.lib().mfx_debug_set_force_generic(1)
+    try:
+        slow = engine.fit_batch(plan, Y, Kv, cm, em, peaks, 2, True, True, sig_csf, sig_ear, E)
+    finally:
+        L.lib().mfx_debug_set_force_generic(0)
+    ref = orc.fit_batch(T, sch, Y, Kv, cm, em, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=8)
+    for got in (slow, fused):
+        g, r = _mask_inactive_ids(got, ref)
+        assert np.array_equal(g[:, [3, 4, 7]], r[:, [3, 4, 7]])
+        assert np.allclose(g, r, rtol=1e-7, atol=1e-9)
+    empty = (Kv == 0) & ~cm & ~em
+    assert empty.any() and np.all(slow[empty] == 0)
+
+
+@pytest.mark.parametrize("case", ["many_ear_columns", "long_protocol", "large_dictionary"])
+def test_shapes_beyond_the_fused_kernels_limits(case):
+    """Shapes the fused kernels refuse (more than 16 CSF+EAR columns; more than 560 measurements; a dictionary whose
+    rotated chunks do not fit the LDS) are fitted all the same, against the CPU restatement."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    from oracle import oracle as orc
+    rng = np.random.default_rng({"many_ear_columns": 5, "long_protocol": 6, "large_dictionary": 7}[case])
+    if case == "many_ear_columns":
+        N, E, V, dirs, kmax = 24, 20, 36, [29, 29], 2
+    elif case == "long_protocol":
+        N, E, V, dirs, kmax = 24, 3, 24, [200, 200, 200], 2
+    else:
+        N, E, V, dirs, kmax = 3000, 2, 3, [66, 66, 66], 2
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000][:len(dirs)], dirs)
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    T = _oracle_tables(ms) | {"scheme_DeldelTE": ms["scheme_DeldelTE"]}
+    sig_csf, sig_ear = _extras(sch, E)
+    Kv, cm, em, peaks, Y = _mixed_voxels(rng, ms, sch, T, N, V, sig_csf, sig_ear, kmax)
+    if case == "large_dictionary":
+        Kv[:] = 2; cm[:] = [False, True, False]; em[:] = False
+        for v in range(V):
+            Y[v] = 400 * (0.6 * orc.interp(sch, peaks[v, :3], T)[:, 7 + v] + 0.4 * orc.interp(sch, peaks[v, 3:], T)[:, 2900 - v]) + rng.normal(0, 10, sch.shape[0])
+    got = engine.fit_batch(ms.plan_for(sch), Y, Kv, cm, em, peaks, 2, True, True, sig_csf, sig_ear, E)
+    ref = orc.fit_batch(T, sch, Y, Kv, cm, em, peaks, 2, True, True, sig_csf, sig_ear, E, nthreads=8)
+    g, r = _mask_inactive_ids(got, ref)
+    assert np.array_equal(g[:, [3, 4, 7]], r[:, [3, 4, 7]])
+    assert np.allclose(g, r, rtol=1e-7, atol=1e-9)
