@@ -54,6 +54,17 @@ typedef float k3_f16v __attribute__((ext_vector_type(16)));
                                    // (5.1 x 2^-24 x ~2.2 |d1||d2| = 6.7e-7), three-half split of u1 u2 (< 1e-8)
 #define MFX_K3M_BIG 60000.0f       // "always pass" factor (FP16 range)
 
+// What the screen needs of an atom d (first or second dictionary) beside a third atom d3, whatever the threshold: d' = d
+// minus its projection on d3, y' likewise; z = d'.y'/|d'|, n = |d'| (0: d is (nearly) inside span(d3): every partner
+// passes), u = d.d3/|d3| in three FP16 halves, the margin slot sqrt(D) |d'|.  Built once per voxel (mfx_k3b_items_kernel);
+// the screen's workgroups - 24 of them share an atom of the first dictionary, 12 one of the second - only add what
+// depends on the running threshold.
+struct K3Item {
+  float z, n;
+  _Float16 uh, um, ul, mg;
+};
+static_assert(sizeof(K3Item) == 16, "K3Item is one 16-byte load");
+
 struct K3BArgs {
   int B, M, N, LD;                 // voxels in the batch, measurements, atoms per dictionary, 3 N
   int cap;                         // candidate list entries in use (<= MFX_K3B_CAP; tests lower it to force the fallback)
@@ -65,6 +76,7 @@ struct K3BArgs {
   double* aty;                     // [B][LD] d.y
   double* ysq;                     // [B][2] sequential, pairwise
   double2* st3;                    // [B][N] 1/|d3|, y.d3/|d3|
+  struct K3Item* items;            // [B][2][ceil(N / KB)][N][KB]: the threshold-independent part of every (atom, third atom) item
   unsigned long long* thr;         // [B] bits of the best score so far
   unsigned long long* seed;        // [B][3] best pair of each dictionary pair: (float score bits << 32) | (p N + q)
   int* ncand;                      // [B][2] candidates appended, overflow flag
@@ -190,8 +202,45 @@ __global__ __launch_bounds__(256) void mfx_k3b_greedy_kernel(K3BArgs k) {
   if ((threadIdx.x & 63) == 0) k3_raise(k.thr + b, best);
 }
 
+// ---- the items of the screen (see K3Item): grid (ceil(N * nblk * KB / 256), 2, B), one thread per (atom, third atom)
+__global__ __launch_bounds__(256) void mfx_k3b_items_kernel(K3BArgs k) {
+  constexpr int KB = MFX_K3M_KB;
+  const int b = blockIdx.z, side = blockIdx.y, N = k.N;
+  const int nblk = (N + KB - 1) / KB;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;       // a * (nblk KB) + k3: the Gram row is read along k3
+  const int a = (int)(e / (nblk * KB)), k3 = (int)(e - (long)a * (nblk * KB));
+  if (a >= N || k3 >= N) return;
+  const long nn = (long)N * N;
+  const double* __restrict__ G3 = k.G + ((size_t)b * 3 + 1 + side) * nn;     // G13 / G23
+  const double2 s3 = k.st3[(size_t)b * N + k3];
+  const double aa = k.nrm2[(size_t)b * k.LD + side * N + a], ya = k.aty[(size_t)b * k.LD + side * N + a];
+  const double u = G3[(size_t)a * N + k3] * s3.x;
+  const double np2 = aa - u * u;                            // |d'|^2
+  const double zn = ya - u * s3.y;                          // d'.y'
+  K3Item it;
+  it.z = 0.0f; it.n = 0.0f; it.mg = (_Float16)0.0f;
+  if (np2 > 1e-10 * aa) {
+    const float n2f = (float)np2, rs = __builtin_amdgcn_rsqf(n2f);
+    it.n = n2f * rs;
+    it.z = (float)zn * rs;
+    it.mg = (_Float16)(__builtin_amdgcn_sqrtf(MFX_K3M_D) * it.n * 1.002f);
+  }
+  {   // u in THREE halves (u = uh + um + ul to 2^-32: the products uh uh, uh um, um uh, um um, uh ul, ul uh leave ~1e-9 |u1 u2|);
+      // u1 u2 nearly cancels a12, so its error is what the accumulator margin is made of
+    float f = (float)u;
+    asm("" : "+v"(f));
+    const float h1 = __uint_as_float(__float_as_uint(f) & 0xffffe000u);
+    const float r1 = f - h1;
+    const float h2 = __uint_as_float(__float_as_uint(r1) & 0xffffe000u);
+    it.uh = (_Float16)h1; it.um = (_Float16)h2; it.ul = (_Float16)(r1 - h2);
+  }
+  k.items[((((size_t)b * 2 + side) * nblk + (k3 / KB)) * N + a) * KB + (k3 % KB)] = it;
+}
+
 // ---- the triple screen on the matrix pipe: grid (ceil(N / 128), ceil(N / 256), B), 512 threads
-__global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs k) {
+// (two waves per SIMD - two workgroups per CU - is what the LDS allows; saying so keeps the accumulators of the matrix
+// instructions in the vector registers the comparisons read, instead of copying 16 registers in and out per instruction)
+__global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfx_k3b_screen_kernel(K3BArgs k) {
   constexpr int KB = MFX_K3M_KB, TI = MFX_K3M_TI, TJ = MFX_K3M_TJ, WGS = TI * 64;
   extern __shared__ double k3m_smem[];
   k3_h8* sA = (k3_h8*)k3m_smem;                          // [2][KB][TI][64]  operands of the i1 side, fragment order
@@ -301,6 +350,29 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
     }
   };
   const int nblk = (N + KB - 1) / KB;
+  // a thread's items of a block: (TI + TJ) x 32 atoms x KB third atoms over WGS threads; WGS is a multiple of KB, so they
+  // all belong to one third atom (k0 + kk).  They are loaded a block ahead: the loads fly behind the multiplications
+  constexpr int NIT = (TI + TJ) * 32 * KB / WGS;
+  static_assert(NIT * WGS == (TI + TJ) * 32 * KB && WGS % KB == 0, "items per thread");
+  const int kk = tid & (KB - 1);
+  K3Item nxt[NIT];
+  double z3n = 0.0;
+  auto load_items = [&](int blk_) {
+    const int k3 = blk_ * KB + kk;
+    const K3Item* __restrict__ itm = k.items + ((size_t)b * 2 * nblk + blk_) * N * KB;
+    const bool okk = blk_ < nblk && k3 < N;
+    z3n = okk ? st3[k3].y : 0.0;
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+      const int al = (tid + r * WGS) / KB;
+      const bool side = al >= TI * 32;
+      const int a = side ? j0 + al - TI * 32 : i0 + al;
+      nxt[r].z = 0.0f; nxt[r].n = -1.0f;                      // n < 0: beyond the dictionary, never passes
+      nxt[r].uh = nxt[r].um = nxt[r].ul = nxt[r].mg = (_Float16)0.0f;
+      if (okk && a < N) nxt[r] = itm[((size_t)(side ? nblk : 0) * N + a) * KB + kk];
+    }
+  };
+  load_items(0);
   for (int blk = 0; blk <= nblk; ++blk) {
     const int buf = blk & 1, k0 = blk * KB;
 #ifdef MFX_K3M_EXP_NOBUILD   // timing experiment (wrong results): operands of the first two blocks only
@@ -312,28 +384,32 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
       // (TI + TJ) x 32 atoms x KB third atoms, 3 items per thread
       const double T = s_T[blk % 3];
       if (tid == 0) s_T[(blk + 1) % 3] = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
-      for (int q = tid; q < (TI + TJ) * 32 * KB; q += WGS) {
-        const int kk = q & (KB - 1), al = q / KB;            // al: atom within the workgroup (i1 side first)
+      K3Item cur[NIT];
+#pragma unroll
+      for (int r = 0; r < NIT; ++r) cur[r] = nxt[r];
+      const double z3 = z3n;
+      const int k3 = k0 + kk;
+      load_items(blk + 1);
+      float Tp = 1e30f, rth = 0.0f, z3f = 0.0f;
+      if (k3 < N) {
+        Tp = (float)(T - z3 * z3) * (1.0f - 2e-7f);         // what the two projected atoms must reach
+        rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 1e-6f);
+        z3f = (float)z3;
+      }
+#pragma unroll
+      for (int r = 0; r < NIT; ++r) {
+        const int al = (tid + r * WGS) / KB;                 // al: atom within the workgroup (i1 side first)
         const bool side = al >= TI * 32;
-        const int k3 = k0 + kk;
-        const int a = side ? j0 + al - TI * 32 : i0 + al;
-        float P = 0.0f, Qv = 0.0f, U = 0.0f, alw = 0.0f, mrgn = 0.0f, zit = -1e30f, nit = 1.0f;   // (beyond the dictionary: never passes)
-        if (a < N && k3 < N) {
-          const double2 s3 = st3[k3];
-          const double in3 = s3.x, z3 = s3.y;
-          const double g3v = (side ? G23 : G13)[(size_t)a * N + k3];
-          const double u = g3v * in3;
-          const double aa = s_aa[al];
-          const double np2 = aa - u * u;                            // |d'|^2
-          const double zn = s_ay[al] - u * z3;                      // d'.y'
-          const float Tp = (float)(T - z3 * z3) * (1.0f - 2e-7f);   // what the two projected atoms must reach
-          U = (float)u;
-          alw = MFX_K3M_BIG;                                        // (nearly) inside span(d3): every partner passes
-          if (np2 > 1e-10 * aa) {
-            const float n2f = (float)np2, rs = __builtin_amdgcn_rsqf(n2f);
-            const float npf = n2f * rs, z = (float)zn * rs;
+        float P = 0.0f, Qv = 0.0f, alw = 0.0f, zit = -1e30f, nit = 1.0f;   // (beyond the dictionary: never passes)
+        _Float16 uh = (_Float16)0.0f, um = uh, ul = uh, mg16 = uh;
+        const K3Item it = cur[r];
+        if (it.n >= 0.0f) {
+          uh = it.uh; um = it.um; ul = it.ul;
+          alw = MFX_K3M_BIG;                                 // (nearly) inside span(d3): every partner passes
+          nit = 0.0f;
+          if (it.n > 0.0f) {
+            const float z = it.z;
             const bool always = !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 3e-6f));
-            const float rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 1e-6f);
             // P = cos theta over the whole range of z: an atom whose projection on the signal is NEGATIVE can still carry a
             // positive weight beside a partner at an obtuse angle (after the projection on d3's complement that is common),
             // and S(c) = T at c = cos(theta1 + theta2) holds for either sign (cos^2 a + cos^2 b - 2 cos(a+b) cos a cos b =
@@ -345,34 +421,20 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
             // one value, s_T[block mod 3], published a block ahead)
             const float Pc = fmaxf(-1.0f, fminf(1.0f, z * rth));
             const float Qc = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-Pc, Pc, 1.0f)));
-            P = Pc * npf;
-            Qv = Qc * npf;
-            mrgn = __builtin_amdgcn_sqrtf(MFX_K3M_D) * npf * 1.002f;
+            P = Pc * it.n;
+            Qv = Qc * it.n;
+            mg16 = it.mg;
             alw = always ? MFX_K3M_BIG : 0.0f;
-            zit = z; nit = always ? 0.0f : npf;
-          } else {
-            nit = 0.0f;
+            zit = z; nit = always ? 0.0f : it.n;
           }
-          if (al == 0) { float* b3 = s_b3 + (buf * KB + kk) * 4; b3[0] = Tp; b3[1] = (float)z3; }   // (item (atom 0, kk) of the i1 side)
-        } else if (al == 0) {
-          float* b3 = s_b3 + (buf * KB + kk) * 4; b3[0] = 1e30f; b3[1] = 0.0f;
         }
+        if (al == 0) { float* b3 = s_b3 + (buf * KB + kk) * 4; b3[0] = Tp; b3[1] = z3f; }   // (item (atom 0, kk) of the i1 side; beyond the dictionary: 1e30)
         s_it[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = float2{zit, nit};
-        s_uu[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = U;
-        // u in THREE halves (u = uh + um + ul to 2^-32: the products uh uh, uh um, um uh, um um, uh ul, ul uh leave ~1e-9 |u1 u2|);
-        // u1 u2 nearly cancels a12, so its error is what the accumulator margin is made of
-        _Float16 ph, pl, qh, ql, uh, um, ul;
+        s_uu[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = ((float)uh + (float)um) + (float)ul;
+        _Float16 ph, pl, qh, ql;
         k3_split16(P, ph, pl);
         k3_split16(Qv, qh, ql);
-        {
-          float f = U;
-          asm("" : "+v"(f));
-          const float h1 = __uint_as_float(__float_as_uint(f) & 0xffffe000u);
-          const float r1 = f - h1;
-          const float h2 = __uint_as_float(__float_as_uint(r1) & 0xffffe000u);
-          uh = (_Float16)h1; um = (_Float16)h2; ul = (_Float16)(r1 - h2);
-        }
-        const _Float16 z0 = (_Float16)0.0f, big = (_Float16)MFX_K3M_BIG, al16 = (_Float16)alw, mg16 = (_Float16)mrgn;
+        const _Float16 z0 = (_Float16)0.0f, big = (_Float16)MFX_K3M_BIG, al16 = (_Float16)alw;
         k3_h8 lo8, hi8;
         if (!side) {   // A operand (rows): P P P' -Q -Q -Q' u u | u' u' u u'' alw BIG 0 0
           lo8 = k3_h8{ph, ph, pl, -qh, -qh, -ql, uh, uh};
@@ -397,7 +459,11 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
         if (tid == 0) s_qn[par] = 0;
       }
     }
+#ifdef MFX_K3M_EXP_NOMFMA   // timing experiment (wrong results): operand build and barriers only
+    if (blk > nblk) {
+#else
     if (blk < nblk) {
+#endif
       const int nk = min(KB, N - k0);
       for (int kk = 0; kk < nk; ++kk) {
         const k3_h8 af = sA[((size_t)(buf * KB + kk) * TI + wave) * 64 + lane];
@@ -405,12 +471,17 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) void mfx_k3b_screen_kernel(K3BArgs
         for (int t = 0; t < TJ; ++t) {
           const k3_h8 bf = sB[((size_t)(buf * KB + kk) * TJ + t) * 64 + lane];
           const k3_f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, C[t], 0, 0, 0);
-          float m = fmaxf(fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), fmaxf(fmaxf(d[4], d[5]), fmaxf(d[6], d[7])));
-          m = fmaxf(m, fmaxf(fmaxf(fmaxf(d[8], d[9]), fmaxf(d[10], d[11])), fmaxf(fmaxf(d[12], d[13]), fmaxf(d[14], d[15]))));
+          // any test value >= 0 in the tile?  As signed integers the bit patterns of non-negative floats are the non-negative
+          // ones: an integer maximum (three operands per instruction, no NaN handling) answers it.  (-0.0 counts as negative:
+          // it would take an accumulator input of exactly -0, and that one carries a positive margin.)
+          int mi = max(max(__float_as_int(d[0]), __float_as_int(d[1])), __float_as_int(d[2]));
+#pragma unroll
+          for (int g = 3; g < 15; g += 2) mi = max(max(mi, __float_as_int(d[g])), __float_as_int(d[g + 1]));
+          mi = max(mi, __float_as_int(d[15]));
 #ifdef MFX_K3M_EXP_NOHIT   // timing experiment (wrong results)
-          if (m > 1e37f) {
+          if (mi == 0x7fffffff) {
 #else
-          if (__any(m >= 0.0f)) {
+          if (__any(mi >= 0)) {
 #endif
             // (rare path) the third atom's weight in the unconstrained optimum, per accumulator register
             // (rare path: the tile has a hit) second test, in registers, before anything is queued: (i) the relaxed two-atom

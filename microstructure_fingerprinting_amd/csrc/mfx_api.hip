@@ -737,6 +737,9 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   HIPCHK(dG.alloc(sizeof(double) * (size_t)BT * 3 * nn));
   HIPCHK(dcol.alloc(sizeof(double) * ((size_t)BT * LD * 2 + (size_t)BT * 2)));
   HIPCHK(dst3.alloc(sizeof(double2) * (size_t)BT * N));
+  const int nblk3 = (N + MFX_K3M_KB - 1) / MFX_K3M_KB;
+  StreamMem ditm(st);
+  HIPCHK(ditm.alloc(sizeof(K3Item) * (size_t)BT * 2 * nblk3 * N * MFX_K3M_KB));
   HIPCHK(dsm.alloc(sizeof(unsigned long long) * (size_t)BT * 8 + sizeof(int) * (size_t)BT * 2));
   const bool k3dbg = getenv("MFX_K3_DEBUG") != nullptr;
   HIPCHK(dcs.alloc(sizeof(double) * (size_t)BT * MFX_K3B_CAP));
@@ -756,6 +759,7 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   k.A = dA.as<double>(); k.Y = d_Y; k.G = dG.as<double>();
   k.nrm2 = dcol.as<double>(); k.aty = k.nrm2 + (size_t)BT * LD; k.ysq = k.aty + (size_t)BT * LD;
   k.st3 = dst3.as<double2>();
+  k.items = ditm.as<K3Item>();
   k.thr = dsm.as<unsigned long long>(); k.seed = k.thr + BT; k.ncand = (int*)(k.seed + 7 * (size_t)BT);
   k.dbg = k3dbg ? k.seed + 3 * (size_t)BT : nullptr;
   k.cand_score = dcs.as<double>(); k.cand_tuple = dct.as<long>();
@@ -797,6 +801,7 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
     hipLaunchKernelGGL(mfx_k3b_stats_kernel, dim3((LD + 255) / 256, B), dim3(256), 0, st, k);
     const int nt = (N + 63) / 64;
     hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3(nt, nt, 3 * B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_items_kernel, dim3((unsigned)(((size_t)N * nblk3 * MFX_K3M_KB + 255) / 256), 2, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_pairs_kernel, dim3(256, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_greedy_kernel, dim3(3, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_screen_kernel, dim3((N + MFX_K3M_TJ * 32 - 1) / (MFX_K3M_TJ * 32), (N + MFX_K3M_TI * 32 - 1) / (MFX_K3M_TI * 32), B),
