@@ -355,26 +355,29 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
   constexpr int NIT = (TI + TJ) * 32 * KB / WGS;
   static_assert(NIT * WGS == (TI + TJ) * 32 * KB && WGS % KB == 0, "items per thread");
   const int kk = tid & (KB - 1);
-  K3Item nxt[NIT];
+  uint4 nxt[NIT];    // (K3Item as four dwords: unpacked where it is used)
   double z3n = 0.0;
-  auto load_items = [&](int blk_) {
-    const int k3 = blk_ * KB + kk;
-    const K3Item* __restrict__ itm = k.items + ((size_t)b * 2 * nblk + blk_) * N * KB;
-    const bool okk = blk_ < nblk && k3 < N;
-    z3n = okk ? st3[k3].y : 0.0;
+  auto load_items = [&](int blk_) {   // (unconditional loads from clamped addresses: nothing here waits for them)
+    const int bq = min(blk_, nblk - 1);
+    const uint4* __restrict__ itm = (const uint4*)k.items + ((size_t)b * 2 * nblk + bq) * N * KB;
+    z3n = st3[min(bq * KB + kk, N - 1)].y;
 #pragma unroll
     for (int r = 0; r < NIT; ++r) {
       const int al = (tid + r * WGS) / KB;
       const bool side = al >= TI * 32;
-      const int a = side ? j0 + al - TI * 32 : i0 + al;
-      nxt[r].z = 0.0f; nxt[r].n = -1.0f;                      // n < 0: beyond the dictionary, never passes
-      nxt[r].uh = nxt[r].um = nxt[r].ul = nxt[r].mg = (_Float16)0.0f;
-      if (okk && a < N) nxt[r] = itm[((size_t)(side ? nblk : 0) * N + a) * KB + kk];
+      const int a = min(side ? j0 + al - TI * 32 : i0 + al, N - 1);
+      nxt[r] = itm[((size_t)(side ? nblk : 0) * N + a) * KB + kk];
     }
   };
   load_items(0);
+  unsigned long long thr_ahead = __hip_atomic_load(thrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (thread 0's)
   for (int blk = 0; blk <= nblk; ++blk) {
     const int buf = blk & 1, k0 = blk * KB;
+    uint4 cur[NIT];
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) cur[r] = nxt[r];
+    const double z3 = z3n;
+    load_items(blk + 1);   // (outside the condition below: a value defined on one side of a branch is copied, and waited for, at its end)
 #ifdef MFX_K3M_EXP_NOBUILD   // timing experiment (wrong results): operands of the first two blocks only
     if (blk < 2) {
 #else
@@ -382,14 +385,14 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
 #endif
       // ---- operands of the block from ONE recent threshold (read by thread 0 a block ahead, behind a barrier):
       // (TI + TJ) x 32 atoms x KB third atoms, 3 items per thread
+      // (the value published for block blk + 1 was requested from memory while block blk - 1 was multiplied: waiting for
+      // the round trip at every block - four waves behind a barrier behind one load - was half of this kernel's time)
       const double T = s_T[blk % 3];
-      if (tid == 0) s_T[(blk + 1) % 3] = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
-      K3Item cur[NIT];
-#pragma unroll
-      for (int r = 0; r < NIT; ++r) cur[r] = nxt[r];
-      const double z3 = z3n;
+      if (tid == 0) {
+        s_T[(blk + 1) % 3] = __longlong_as_double((long long)thr_ahead) - eps_abs;
+        thr_ahead = __hip_atomic_load(thrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const int k3 = k0 + kk;
-      load_items(blk + 1);
       float Tp = 1e30f, rth = 0.0f, z3f = 0.0f;
       if (k3 < N) {
         Tp = (float)(T - z3 * z3) * (1.0f - 2e-7f);         // what the two projected atoms must reach
@@ -402,8 +405,12 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
         const bool side = al >= TI * 32;
         float P = 0.0f, Qv = 0.0f, alw = 0.0f, zit = -1e30f, nit = 1.0f;   // (beyond the dictionary: never passes)
         _Float16 uh = (_Float16)0.0f, um = uh, ul = uh, mg16 = uh;
-        const K3Item it = cur[r];
-        if (it.n >= 0.0f) {
+        typedef _Float16 k3_h2 __attribute__((ext_vector_type(2)));
+        K3Item it;
+        it.z = __uint_as_float(cur[r].x); it.n = __uint_as_float(cur[r].y);
+        { const k3_h2 h = __builtin_bit_cast(k3_h2, cur[r].z); it.uh = h[0]; it.um = h[1]; }
+        { const k3_h2 h = __builtin_bit_cast(k3_h2, cur[r].w); it.ul = h[0]; it.mg = h[1]; }
+        if (k3 < N && (side ? j0 + al - TI * 32 : i0 + al) < N) {
           uh = it.uh; um = it.um; ul = it.ul;
           alw = MFX_K3M_BIG;                                 // (nearly) inside span(d3): every partner passes
           nit = 0.0f;
@@ -533,6 +540,11 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
         }
       }
     }
+    // the next block's items and third-atom constant are first touched here, behind the multiplications: the wait for
+    // their loads (issued before this block's operands were built) goes here instead of in front of the barrier
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) asm volatile("" : "+v"(nxt[r].x), "+v"(nxt[r].y), "+v"(nxt[r].z), "+v"(nxt[r].w));
+    asm volatile("" : "+v"(z3n));
   }
 }
 
