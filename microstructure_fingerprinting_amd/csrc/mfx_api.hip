@@ -724,7 +724,7 @@ static int launch_solver(SolveArgs a, const K3Bufs* k3, hipStream_t st) {
 }
 
 // Three fascicles without extra columns (BASELINE config 5) in batches of voxels: fit_k3.hip.  Everything is enqueued on `st`.
-#define MFX_K3B_BATCH 8
+#define MFX_K3B_BATCH 16
 static bool k3b_applies(int K, int NX, int N, long ntuples) { return K == 3 && NX == 0 && N >= 32 && ntuples >= (1L << 18); }
 static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list, int nvox,
                           int maxfasc, int csf_on, int ear_on, double* d_params, hipStream_t st) {
@@ -793,11 +793,8 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   for (int q0 = 0; q0 < nvox; q0 += BT) {
     const int B = std::min(BT, nvox - q0);
     k.B = B; k.vox = dvox.as<int>() + q0;
-    for (int b = 0; b < B; ++b) {
-      const long v = h_list ? h_list[q0 + b] : q0 + b;
-      hipLaunchKernelGGL(mfx_rotate_kernel, dim3((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, 3), dim3(MFX_ROT_WG), 0, st, p->t->d, p->d,
-                         d_peaks + (size_t)v * peaks_ld, 0, dA.as<double>() + (size_t)b * M * LD, (long)N, (long)LD);
-    }
+    hipLaunchKernelGGL(mfx_rotate_voxels_kernel, dim3((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, 3, B), dim3(MFX_ROT_WG), 0, st, p->t->d, p->d,
+                       d_peaks, peaks_ld, k.vox, dA.as<double>());
     hipLaunchKernelGGL(mfx_k3b_stats_kernel, dim3((LD + 255) / 256, B), dim3(256), 0, st, k);
     const int nt = (N + 63) / 64;
     hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3(nt, nt, 3 * B), dim3(256), 0, st, k);

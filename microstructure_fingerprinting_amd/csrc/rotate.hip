@@ -12,18 +12,15 @@
 
 // out[b * bstride + m * rstride + n] (b-major [B x M x N]: bstride = M N, rstride = N; sub-dictionary b of a row-major
 // [M x K N] matrix: bstride = N, rstride = K N), one workgroup per (direction b, block of MFX_ROT_ROWS protocol rows)
-__global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, PlanDev P, const double* __restrict__ dirs,
-                                                                int normalise, double* __restrict__ out, long bstride,
-                                                                long rstride) {
+__device__ __forceinline__ void mfx_rotate_block(const TablesDev& T, const PlanDev& P, const double* __restrict__ dir3,
+                                                 int normalise, double* __restrict__ out, long rstride, int m0) {
   __shared__ RowDesc s_rd[MFX_ROT_ROWS];
   __shared__ double s_tG[MFX_ROT_ROWS], s_dG[MFX_ROT_ROWS];
-  const int b = blockIdx.y;
-  const int m0 = blockIdx.x * MFX_ROT_ROWS;
   const int M = P.M, N = T.N, ldn = T.ldn;
   if (threadIdx.x < MFX_ROT_ROWS) {
     const int m = m0 + threadIdx.x;
     if (m < M) {
-      double d0 = dirs[3 * (size_t)b], d1 = dirs[3 * (size_t)b + 1], d2 = dirs[3 * (size_t)b + 2];
+      double d0 = dir3[0], d1 = dir3[1], d2 = dir3[2];
       if (normalise && !P.normalise) {  // rotate_atom: newdir / |newdir| (mf_utils.py:1262,1269); explicit plans do it in mfx_row_desc
         const double nn = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
         d0 /= nn; d1 /= nn; d2 /= nn;
@@ -37,8 +34,25 @@ __global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, Pla
   const int rows = min(MFX_ROT_ROWS, M - m0);
   for (int idx = threadIdx.x; idx < rows * N; idx += MFX_ROT_WG) {
     const int r = idx / N, n = idx - r * N;
-    out[(size_t)b * bstride + (size_t)(m0 + r) * rstride + n] = mfx_eval_br(T.tab, ldn, s_rd[r], s_tG[r], s_dG[r], n);
+    out[(size_t)(m0 + r) * rstride + n] = mfx_eval_br(T.tab, ldn, s_rd[r], s_tG[r], s_dG[r], n);
   }
+}
+
+__global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_kernel(TablesDev T, PlanDev P, const double* __restrict__ dirs,
+                                                                int normalise, double* __restrict__ out, long bstride,
+                                                                long rstride) {
+  const int b = blockIdx.y;
+  mfx_rotate_block(T, P, dirs + 3 * (size_t)b, normalise, out + (size_t)b * bstride, rstride, blockIdx.x * MFX_ROT_ROWS);
+}
+
+// The K rotated dictionaries of a batch of voxels, each voxel's as one row-major [M x K N] matrix (grid (rows, K, voxels)):
+// voxel vox[z]'s fascicle y along peaks[vox[z] * peaks_ld + 3 y ..], into out + z * M * K * N, columns y N ..
+__global__ __launch_bounds__(MFX_ROT_WG) void mfx_rotate_voxels_kernel(TablesDev T, PlanDev P, const double* __restrict__ peaks,
+                                                                       int peaks_ld, const int* __restrict__ vox,
+                                                                       double* __restrict__ out) {
+  const long LD = (long)gridDim.y * T.N;
+  mfx_rotate_block(T, P, peaks + (size_t)vox[blockIdx.z] * peaks_ld + 3 * blockIdx.y, 0,
+                   out + (size_t)blockIdx.z * P.M * LD + (size_t)blockIdx.y * T.N, LD, blockIdx.x * MFX_ROT_ROWS);
 }
 
 // out[b][m] = rotated atom cols[b] only (one atom per direction); thread per (b, m)
