@@ -42,7 +42,11 @@ extern "C" {
 #define MFX_ERR_G_RANGE 2      /* mf_utils.py:1829-1836 "Extrapolation not supported" -> ValueError */
 #define MFX_ERR_NO_DEVICE 3    /* no usable HIP device -> RuntimeError */
 #define MFX_ERR_HIP 4          /* HIP runtime failure -> RuntimeError */
-#define MFX_ERR_UNSUPPORTED 5  /* shape outside the kernels' limits -> NotImplementedError */
+#define MFX_ERR_UNSUPPORTED 5  /* shape outside a kernel's limits -> NotImplementedError.  The voxel loop (mfx_fit_batch*) does
+                                * not return it for large dictionaries, long protocols or many CSF+EAR columns: those classes
+                                * run voxel by voxel through the explicit-dictionary solver (slow, same results); it remains for
+                                * mfx_solve_exhaustive (> 8 sub-dictionaries, > 2^40 index tuples, > 30000 columns) and the
+                                * launch limits of mfx_monte_carlo_average */
 #define MFX_ERR_DIR_NORM 6     /* mf_utils.py:1798-1802 non-unit fascicle direction -> ValueError */
 
 typedef struct mfx_tables mfx_tables; /* device-resident per-shell knot tables */
@@ -50,7 +54,8 @@ typedef struct mfx_plan mfx_plan;     /* device-resident per-protocol row plan  
 
 const char* mfx_last_error(void);
 int mfx_device_count(void);
-/* library/ABI version, bumped on any signature change */
+/* library/ABI version, bumped on any signature change or new entry point (3: mfx_fit_batch_volume, counters 8-10 of
+ * mfx_debug_last_counter, mfx_debug_set_k3_cap, mfx_debug_set_force_generic) */
 int mfx_abi_version(void);
 
 /* ---- tables: replaces the interpolator objects returned by

@@ -196,7 +196,7 @@ static int fb_read(int which) {
 }
 
 extern "C" const char* mfx_last_error(void) { return mfx_thread().err.c_str(); }
-extern "C" int mfx_abi_version(void) { return 2; }
+extern "C" int mfx_abi_version(void) { return 3; }
 extern "C" int mfx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

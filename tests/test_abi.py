@@ -25,7 +25,7 @@ def test_exports_match_header():
     for name in decl:
         assert hasattr(lib, name), "libmfx.so lacks %s declared in include/mfx.h" % name
     assert sorted(L.EXPORTS) == decl, "python binding list out of sync with include/mfx.h"
-    assert lib.mfx_abi_version() == 2
+    assert lib.mfx_abi_version() == 3
 
 
 def test_no_device_fails_loudly():
