@@ -399,63 +399,62 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
         rth = __builtin_amdgcn_rsqf(fmaxf(Tp, 1e-30f)) * (1.0f + 1e-6f);
         z3f = (float)z3;
       }
-#pragma unroll
-      for (int r = 0; r < NIT; ++r) {
-        const int al = (tid + r * WGS) / KB;                 // al: atom within the workgroup (i1 side first)
-        const bool side = al >= TI * 32;
-        float P = 0.0f, Qv = 0.0f, alw = 0.0f, zit = -1e30f, nit = 1.0f;   // (beyond the dictionary: never passes)
-        _Float16 uh = (_Float16)0.0f, um = uh, ul = uh, mg16 = uh;
-        typedef _Float16 k3_h2 __attribute__((ext_vector_type(2)));
-        K3Item it;
-        it.z = __uint_as_float(cur[r].x); it.n = __uint_as_float(cur[r].y);
-        { const k3_h2 h = __builtin_bit_cast(k3_h2, cur[r].z); it.uh = h[0]; it.um = h[1]; }
-        { const k3_h2 h = __builtin_bit_cast(k3_h2, cur[r].w); it.ul = h[0]; it.mg = h[1]; }
-        if (k3 < N && (side ? j0 + al - TI * 32 : i0 + al) < N) {
-          uh = it.uh; um = it.um; ul = it.ul;
-          alw = MFX_K3M_BIG;                                 // (nearly) inside span(d3): every partner passes
-          nit = 0.0f;
-          if (it.n > 0.0f) {
-            const float z = it.z;
-            const bool always = !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 3e-6f));
-            // P = cos theta over the whole range of z: an atom whose projection on the signal is NEGATIVE can still carry a
-            // positive weight beside a partner at an obtuse angle (after the projection on d3's complement that is common),
-            // and S(c) = T at c = cos(theta1 + theta2) holds for either sign (cos^2 a + cos^2 b - 2 cos(a+b) cos a cos b =
-            // sin^2(a+b)); clamping z at 0 (solve_k3.hip) keeps the test valid but lets every sufficiently obtuse pair of
-            // such an atom through: 1e7 .. 3e8 triples per voxel in voxels with a flat optimum.  The margin D |d1'||d2'| has
-            // its own k-slot (the folding of fit_k2s.hip assumes P >= 0).
-            // (valid for either sign of z only if both atoms of a test see the SAME threshold - for z > 0 a lower threshold
-            // lets more pairs through, for z < 0, where theta decreases with T, fewer: all items of a block are built from
-            // one value, s_T[block mod 3], published a block ahead)
-            const float Pc = fmaxf(-1.0f, fminf(1.0f, z * rth));
-            const float Qc = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-Pc, Pc, 1.0f)));
-            P = Pc * it.n;
-            Qv = Qc * it.n;
-            mg16 = it.mg;
-            alw = always ? MFX_K3M_BIG : 0.0f;
-            zit = z; nit = always ? 0.0f : it.n;
-          }
-        }
+      // Straight-line code, selects instead of branches (the branchy form spent a third of its vector instructions
+      // re-initialising defaults on every path); which operand an item belongs to is known at compile time: a thread's
+      // r-th item is atom (tid + r WGS) / KB of the workgroup, the i1 side first.
+      mfx_static_for<0, NIT>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr bool side = (r * WGS) / KB >= TI * 32;
+        static_assert((TI * 32 * KB) % WGS == 0, "an item index r belongs to one side");
+        const int al = (tid + r * WGS) / KB;                 // al: atom within the workgroup
+        const bool valid = (k3 < N) && ((side ? j0 + al - TI * 32 : i0 + al) < N);   // beyond the dictionary: never passes
+        const float z = __uint_as_float(cur[r].x), nrm = __uint_as_float(cur[r].y);
+        const bool has = valid && nrm > 0.0f;                // (valid, nrm == 0: (nearly) inside span(d3), every partner passes)
+        const bool always = !(Tp > 0.0f) || (z > 0.0f && z * z >= Tp * (1.0f - 3e-6f));
+        // P = cos theta over the whole range of z: an atom whose projection on the signal is NEGATIVE can still carry a
+        // positive weight beside a partner at an obtuse angle (after the projection on d3's complement that is common),
+        // and S(c) = T at c = cos(theta1 + theta2) holds for either sign (cos^2 a + cos^2 b - 2 cos(a+b) cos a cos b =
+        // sin^2(a+b)); clamping z at 0 (solve_k3.hip) keeps the test valid but lets every sufficiently obtuse pair of
+        // such an atom through: 1e7 .. 3e8 triples per voxel in voxels with a flat optimum.  The margin D |d1'||d2'| has
+        // its own k-slot (the folding of fit_k2s.hip assumes P >= 0).
+        // (valid for either sign of z only if both atoms of a test see the SAME threshold - for z > 0 a lower threshold
+        // lets more pairs through, for z < 0, where theta decreases with T, fewer: all items of a block are built from
+        // one value, s_T[block mod 3], published a block ahead)
+        const float Pc = __builtin_amdgcn_fmed3f(z * rth, -1.0f, 1.0f);
+        const float Qc = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-Pc, Pc, 1.0f)));
+        const float P = has ? Pc * nrm : 0.0f, Qv = has ? Qc * nrm : 0.0f;
+        const bool alw = valid && !(has && !always);
+        const unsigned uw = valid ? cur[r].z : 0u;           // halves (uh, um) of u
+        const unsigned lw = valid ? cur[r].w : 0u;           // halves (ul, margin slot); the margin is 0 unless nrm > 0
         if (al == 0) { float* b3 = s_b3 + (buf * KB + kk) * 4; b3[0] = Tp; b3[1] = z3f; }   // (item (atom 0, kk) of the i1 side; beyond the dictionary: 1e30)
-        s_it[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = float2{zit, nit};
-        s_uu[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = ((float)uh + (float)um) + (float)ul;
+        s_it[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = float2{has ? z : -1e30f, valid ? ((has && !always) ? nrm : 0.0f) : 1.0f};
+        typedef _Float16 k3_h2 __attribute__((ext_vector_type(2)));
+        {
+          const k3_h2 u01 = __builtin_bit_cast(k3_h2, uw), u2m = __builtin_bit_cast(k3_h2, lw);
+          s_uu[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = ((float)u01[0] + (float)u01[1]) + (float)u2m[0];
+        }
         _Float16 ph, pl, qh, ql;
         k3_split16(P, ph, pl);
         k3_split16(Qv, qh, ql);
-        const _Float16 z0 = (_Float16)0.0f, big = (_Float16)MFX_K3M_BIG, al16 = (_Float16)alw;
-        k3_h8 lo8, hi8;
-        if (!side) {   // A operand (rows): P P P' -Q -Q -Q' u u | u' u' u u'' alw BIG 0 0
-          lo8 = k3_h8{ph, ph, pl, -qh, -qh, -ql, uh, uh};
-          hi8 = k3_h8{um, um, uh, ul, al16, big, mg16, z0};
-          k3_h8* dst = sA + ((size_t)(buf * KB + kk) * TI + (al >> 5)) * 64 + (al & 31);
+        const unsigned php = __builtin_bit_cast(unsigned short, ph), plp = __builtin_bit_cast(unsigned short, pl);
+        const unsigned qhp = __builtin_bit_cast(unsigned short, qh), qlp = __builtin_bit_cast(unsigned short, ql);
+        constexpr unsigned BIGH = 0x7b53u;                   // 60000 in FP16 (MFX_K3M_BIG)
+        static_assert(MFX_K3M_BIG == 60000.0f, "BIGH is MFX_K3M_BIG in FP16");
+        uint4 lo8, hi8;
+        if constexpr (!side) {   // A operand (rows): P P P' -Q -Q -Q' u u | u' u' u u'' alw BIG margin 0
+          const unsigned nqh = qhp ^ 0x8000u, nql = qlp ^ 0x8000u;
+          lo8 = uint4{php | (php << 16), plp | (nqh << 16), nqh | (nql << 16), (uw & 0xffffu) | (uw << 16)};
+          hi8 = uint4{(uw >> 16) | (uw & 0xffff0000u), (uw & 0xffffu) | (lw << 16), alw ? (BIGH | (BIGH << 16)) : (BIGH << 16), lw >> 16};
+          uint4* dst = (uint4*)sA + ((size_t)(buf * KB + kk) * TI + (al >> 5)) * 64 + (al & 31);
           dst[0] = lo8; dst[32] = hi8;
-        } else {       // B operand (columns): P P' P Q Q' Q u u' | u u' u'' u BIG alw 0 0
+        } else {                 // B operand (columns): P P' P Q Q' Q u u' | u u' u'' u BIG alw margin 0
           const int bl = al - TI * 32;
-          lo8 = k3_h8{ph, pl, ph, qh, ql, qh, uh, um};
-          hi8 = k3_h8{uh, um, ul, uh, big, al16, mg16, z0};
-          k3_h8* dst = sB + ((size_t)(buf * KB + kk) * TJ + (bl >> 5)) * 64 + (bl & 31);
+          lo8 = uint4{php | (plp << 16), php | (qhp << 16), qlp | (qhp << 16), uw};
+          hi8 = uint4{uw, (lw & 0xffffu) | (uw << 16), alw ? (BIGH | (BIGH << 16)) : BIGH, lw >> 16};
+          uint4* dst = (uint4*)sB + ((size_t)(buf * KB + kk) * TJ + (bl >> 5)) * 64 + (bl & 31);
           dst[0] = lo8; dst[32] = hi8;
         }
-      }
+      });
     }
     __syncthreads();   // the block's operands are in place; every push of the previous block is in its queue
     if (blk >= 1) {
