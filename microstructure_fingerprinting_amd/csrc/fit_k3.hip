@@ -49,6 +49,7 @@ typedef float k3_f16v __attribute__((ext_vector_type(16)));
 #ifndef MFX_K3M_Q
 #define MFX_K3M_Q 1024             // queue entries per block parity
 #endif
+#define MFX_K3M_PAD 4              // 16-byte entries of padding behind every operand slot
 #define MFX_K3M_D 8e-6f            // margin in units of |d1'||d2'|: the FP32 constants (4e-6, as solve_k3.hip) + the split of P and Q
 #define MFX_K3M_C 1.0e-6           // margin in units of |d1||d2|: FP32 rounding of a12 and u (1.8e-7), summation inside the pipe
                                    // (5.1 x 2^-24 x ~2.2 |d1||d2| = 6.7e-7), three-half split of u1 u2 (< 1e-8)
@@ -243,9 +244,12 @@ __global__ __launch_bounds__(256) void mfx_k3b_items_kernel(K3BArgs k) {
 __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mfx_k3b_screen_kernel(K3BArgs k) {
   constexpr int KB = MFX_K3M_KB, TI = MFX_K3M_TI, TJ = MFX_K3M_TJ, WGS = TI * 64;
   extern __shared__ double k3m_smem[];
-  k3_h8* sA = (k3_h8*)k3m_smem;                          // [2][KB][TI][64]  operands of the i1 side, fragment order
-  k3_h8* sB = sA + 2 * KB * TI * 64;                       // [2][KB][TJ][64]
-  double* s_aa = (double*)(sB + 2 * KB * TJ * 64);         // [(TI + TJ) * 32] |d|^2 of the workgroup's atoms (0: beyond the dictionary)
+  // (operand slots padded by 64 bytes: the four lanes that build one atom's items for the block's four third atoms store
+  // 16 bytes each a whole slot apart - without the padding into the same banks: 54 % of the LDS cycles were conflicts)
+  constexpr int SA = TI * 64 + MFX_K3M_PAD, SB = TJ * 64 + MFX_K3M_PAD;
+  k3_h8* sA = (k3_h8*)k3m_smem;                          // [2][KB][SA]  operands of the i1 side, fragment order: [TI][64] + padding
+  k3_h8* sB = sA + 2 * KB * SA;                            // [2][KB][SB]
+  double* s_aa = (double*)(sB + 2 * KB * SB);              // [(TI + TJ) * 32] |d|^2 of the workgroup's atoms (0: beyond the dictionary)
   double* s_ay = s_aa + (TI + TJ) * 32;                    // [(TI + TJ) * 32] d.y
   float2* s_it = (float2*)(s_ay + (TI + TJ) * 32);         // [2][(TI + TJ) * 32][KB] {z', |d'|} of the block's (atom, third atom) items (|d'| = 0: always pass)
   float* s_uu = (float*)(s_it + 2 * (TI + TJ) * 32 * KB);  // [2][(TI + TJ) * 32][KB] u = d.d3/|d3| (FP32)
@@ -445,13 +449,13 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
           const unsigned nqh = qhp ^ 0x8000u, nql = qlp ^ 0x8000u;
           lo8 = uint4{php | (php << 16), plp | (nqh << 16), nqh | (nql << 16), (uw & 0xffffu) | (uw << 16)};
           hi8 = uint4{(uw >> 16) | (uw & 0xffff0000u), (uw & 0xffffu) | (lw << 16), alw ? (BIGH | (BIGH << 16)) : (BIGH << 16), lw >> 16};
-          uint4* dst = (uint4*)sA + ((size_t)(buf * KB + kk) * TI + (al >> 5)) * 64 + (al & 31);
+          uint4* dst = (uint4*)sA + (size_t)(buf * KB + kk) * SA + (al >> 5) * 64 + (al & 31);
           dst[0] = lo8; dst[32] = hi8;
         } else {                 // B operand (columns): P P' P Q Q' Q u u' | u u' u'' u BIG alw margin 0
           const int bl = al - TI * 32;
           lo8 = uint4{php | (plp << 16), php | (qhp << 16), qlp | (qhp << 16), uw};
           hi8 = uint4{uw, (lw & 0xffffu) | (uw << 16), alw ? (BIGH | (BIGH << 16)) : BIGH, lw >> 16};
-          uint4* dst = (uint4*)sB + ((size_t)(buf * KB + kk) * TJ + (bl >> 5)) * 64 + (bl & 31);
+          uint4* dst = (uint4*)sB + (size_t)(buf * KB + kk) * SB + (bl >> 5) * 64 + (bl & 31);
           dst[0] = lo8; dst[32] = hi8;
         }
       });
@@ -472,10 +476,10 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
 #endif
       const int nk = min(KB, N - k0);
       for (int kk = 0; kk < nk; ++kk) {
-        const k3_h8 af = sA[((size_t)(buf * KB + kk) * TI + wave) * 64 + lane];
+        const k3_h8 af = sA[(size_t)(buf * KB + kk) * SA + wave * 64 + lane];
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
-          const k3_h8 bf = sB[((size_t)(buf * KB + kk) * TJ + t) * 64 + lane];
+          const k3_h8 bf = sB[(size_t)(buf * KB + kk) * SB + t * 64 + lane];
           const k3_f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, C[t], 0, 0, 0);
           // any test value >= 0 in the tile?  As signed integers the bit patterns of non-negative floats are the non-negative
           // ones: an integer maximum (three operands per instruction, no NaN handling) answers it.  (-0.0 counts as negative:
