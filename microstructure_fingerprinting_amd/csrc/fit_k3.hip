@@ -116,45 +116,84 @@ __global__ __launch_bounds__(256) void mfx_k3b_stats_kernel(K3BArgs k) {
   }
 }
 
-// ---- the three cross blocks of the Gram on FP64 MFMA (ranking only): grid (N/64, N/64, 3 B), one wave = 16 x 64 outputs
+// ---- the three cross blocks of the Gram on FP64 MFMA (ranking only): grid (N/64, N/128, 3 B), one wave = 32 x 64 outputs
+// (two row fragments x four column fragments per k-step: 6 operand loads per 8 MFMAs; with 16 x 64 per wave it was 5 per 4
+// and the kernel ran at the rate of its loads)
 __global__ __launch_bounds__(256) void mfx_k3b_gram_kernel(K3BArgs k) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane >> 4, lc = lane & 15;
-  const int b = blockIdx.z / 3, which = blockIdx.z % 3;
+  // Workgroups go to the 8 XCDs round-robin by their linear index, and each XCD has its own L2: the tiles of ONE matrix
+  // (they share its operand columns) are dealt to ONE XCD - linear index l -> matrix 8 (l / (8 T)) + l % 8, tile (l / 8) % T
+  // - instead of every XCD streaming every matrix (the last, incomplete group of matrices keeps the plain order)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned T = gridDim.x * gridDim.y, l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned grp = l / (8 * T);
+    if (8 * (grp + 1) <= gridDim.z) {
+      const unsigned tl = (l / 8) % T;
+      bz = (int)(8 * grp + l % 8); bx = (int)(tl % gridDim.x); by = (int)(tl / gridDim.x);
+    }
+  }
+  const int b = bz / 3, which = bz % 3;
   const int N = k.N, M = k.M, LD = k.LD;
   const int cp = (which == 2) ? N : 0, cq = (which == 0) ? N : 2 * N;   // column offsets of the row / column dictionary
-  const int p0 = blockIdx.y * 64 + wave * 16, q0 = blockIdx.x * 64;
+  const int p0 = by * 128 + wave * 32, q0 = bx * 64;
   if (p0 >= N) return;
   const double* __restrict__ A = k.A + (size_t)b * M * LD;
-  k3_d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  const int pi = cp + min(p0 + lc, N - 1);
-  int qj[4];
+  k3_d4 acc[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[s][t] = k3_d4{0, 0, 0, 0};
+  int pi[2], qj[4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) pi[s] = cp + min(p0 + 16 * s + lc, N - 1);
 #pragma unroll
   for (int t = 0; t < 4; ++t) qj[t] = cq + min(q0 + 16 * t + lc, N - 1);
-  // two k-steps of operands in flight: the loads of step s+1 fly behind the MFMAs of step s
-  double av = (lg < M) ? A[(size_t)lg * LD + pi] : 0.0, bv[4];
+  // Operands of the NEXT group of U k-steps are requested before the current group is multiplied: a k-step is 8 MFMAs =
+  // 512 cycles of the pipe, a load from L2 / HBM takes 1 500-5 000 - with one k-step in flight the kernel ran at the
+  // rate of its load latency (31 TFLOP/s whatever the tile shape or the placement of the tiles on the XCDs)
+  constexpr int U = 4;
+  double av[U][2], bv[U][4];
+  auto load_group = [&](int kbase, double (&a)[U][2], double (&bb)[U][4]) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) bv[t] = (lg < M) ? A[(size_t)lg * LD + qj[t]] : 0.0;
-  for (int k0 = 0; k0 < M; k0 += 4) {
-    const int kn = k0 + 4 + lg;
-    const bool okn = kn < M;
-    const double avn = okn ? A[(size_t)kn * LD + pi] : 0.0;
-    double bvn[4];
+    for (int u = 0; u < U; ++u) {
+      const int kr = kbase + 4 * u + lg;
+      const bool ok = kr < M;
+      const size_t ro = (size_t)min(kr, M - 1) * LD;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bvn[t] = okn ? A[(size_t)kn * LD + qj[t]] : 0.0;
+      for (int s = 0; s < 2; ++s) { const double v = A[ro + pi[s]]; a[u][s] = ok ? v : 0.0; }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], acc[t], 0, 0, 0);
-    av = avn;
+      for (int t = 0; t < 4; ++t) { const double v = A[ro + qj[t]]; bb[u][t] = ok ? v : 0.0; }
+    }
+  };
+  load_group(0, av, bv);
+  for (int k0 = 0; k0 < M; k0 += 4 * U) {
+    double avn[U][2], bvn[U][4];
+    load_group(k0 + 4 * U, avn, bvn);      // (beyond M: clamped addresses, zeros)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bv[t] = bvn[t];
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[s][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][s], bv[u][t], acc[s][t], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) av[u][s] = avn[u][s];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[u][t] = bvn[u][t];
+    }
   }
   double* __restrict__ G = k.G + ((size_t)b * 3 + which) * N * N;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = p0 + lg + 4 * r, q = q0 + 16 * t + lc;
-      if (p < N && q < N) G[(size_t)p * N + q] = acc[t][r];
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = p0 + 16 * s + lg + 4 * r, q = q0 + 16 * t + lc;
+        if (p < N && q < N) G[(size_t)p * N + q] = acc[s][t][r];
+      }
 }
 
 // ---- threshold seed, step 1: the best pair of each of the three dictionary pairs (FP32 ranking of score2), grid (x, B)

@@ -796,8 +796,7 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
     hipLaunchKernelGGL(mfx_rotate_voxels_kernel, dim3((M + MFX_ROT_ROWS - 1) / MFX_ROT_ROWS, 3, B), dim3(MFX_ROT_WG), 0, st, p->t->d, p->d,
                        d_peaks, peaks_ld, k.vox, dA.as<double>());
     hipLaunchKernelGGL(mfx_k3b_stats_kernel, dim3((LD + 255) / 256, B), dim3(256), 0, st, k);
-    const int nt = (N + 63) / 64;
-    hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3(nt, nt, 3 * B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3((N + 63) / 64, (N + 127) / 128, 3 * B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_items_kernel, dim3((unsigned)(((size_t)N * nblk3 * MFX_K3M_KB + 255) / 256), 2, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_pairs_kernel, dim3(256, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_greedy_kernel, dim3(3, B), dim3(256), 0, st, k);
