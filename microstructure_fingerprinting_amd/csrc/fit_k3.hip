@@ -197,28 +197,26 @@ __global__ __launch_bounds__(256) void mfx_k3b_gram_kernel(K3BArgs k) {
 }
 
 // ---- threshold seed, step 1: the best pair of each of the three dictionary pairs (FP32 ranking of score2), grid (x, B)
-__global__ __launch_bounds__(256) void mfx_k3b_pairs_kernel(K3BArgs k) {
-  const int b = blockIdx.y, N = k.N;
+__global__ __launch_bounds__(256) void mfx_k3b_pairs_kernel(K3BArgs k) {   // grid (ceil(N / 8), 3, B): 8 rows of one cross block
+  const int b = blockIdx.z, which = blockIdx.y, N = k.N;
   const double* __restrict__ n2 = k.nrm2 + (size_t)b * k.LD;
   const double* __restrict__ ay = k.aty + (size_t)b * k.LD;
   const long nn = (long)N * N;
-  unsigned long long best[3] = {0ull, 0ull, 0ull};
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < 3 * nn; idx += (long)gridDim.x * 256) {
-    const int which = (int)(idx / nn);
-    const long e = idx - which * nn;
-    const int p = (int)(e / N), q = (int)(e - (long)p * N);
-    const int cp = (which == 2) ? N + p : p, cq = (which == 0) ? N + q : 2 * N + q;
-    const double s = score2(n2[cp], k.G[((size_t)b * 3 + which) * nn + e], n2[cq], ay[cp], ay[cq]);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf((float)s, 0.0f)) << 32) | (unsigned long long)e;
-    if (key > best[which]) best[which] = key;
+  const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
+  unsigned long long best = 0ull;
+  if (p < N) {
+    const int cp = (which == 2) ? N + p : p, cq0 = (which == 0) ? N : 2 * N;
+    const double a11 = n2[cp], y1 = ay[cp];
+    const double* __restrict__ Gp = k.G + ((size_t)b * 3 + which) * nn + (size_t)p * N;
+    for (int q = threadIdx.x & 31; q < N; q += 32) {
+      const double s = score2(a11, Gp[q], n2[cq0 + q], y1, ay[cq0 + q]);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf((float)s, 0.0f)) << 32) | (unsigned long long)((long)p * N + q);
+      if (key > best) best = key;
+    }
   }
 #pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    unsigned long long v = best[w];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(v, o); v = u > v ? u : v; }
-    if ((threadIdx.x & 63) == 0 && (v >> 32)) atomicMax(&k.seed[3 * b + w], v);
-  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = __shfl_xor(best, o); best = u > best ? u : best; }
+  if ((threadIdx.x & 63) == 0 && (best >> 32)) atomicMax(&k.seed[3 * b + which], best);
 }
 // ---- step 2: the best third atom for each of those pairs; the best of the three triples (and pairs) starts the threshold
 __global__ __launch_bounds__(256) void mfx_k3b_greedy_kernel(K3BArgs k) {

@@ -723,6 +723,20 @@ static int launch_solver(SolveArgs a, const K3Bufs* k3, hipStream_t st) {
   return MFX_OK;
 }
 
+// internal streams of the calling thread (forked from and joined to the caller's stream by events): two voxels in flight
+// on the voxel-by-voxel path, the gated fallback sequences of the batched three-fascicle path
+static int lanes_setup(int device) {
+  MfxThread& T = mfx_thread();
+  if (T.lane_device != device) {
+    for (int l = 0; l < 4; ++l) { if (T.s_lane[l]) (void)hipStreamDestroy(T.s_lane[l]); T.s_lane[l] = nullptr; }
+    for (int l = 0; l < 5; ++l) { if (T.ev_lane[l]) (void)hipEventDestroy(T.ev_lane[l]); T.ev_lane[l] = nullptr; }
+    for (int l = 0; l < 4; ++l) HIPCHK(hipStreamCreateWithFlags(&T.s_lane[l], hipStreamNonBlocking));
+    for (int l = 0; l < 5; ++l) HIPCHK(hipEventCreateWithFlags(&T.ev_lane[l], hipEventDisableTiming));
+    T.lane_device = device;
+  }
+  return MFX_OK;
+}
+
 // Three fascicles without extra columns (BASELINE config 5) in batches of voxels: fit_k3.hip.  Everything is enqueued on `st`.
 #define MFX_K3B_BATCH 16
 static bool k3b_applies(int K, int NX, int N, long ntuples) { return K == 3 && NX == 0 && N >= 32 && ntuples >= (1L << 18); }
@@ -774,21 +788,38 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   // fallback of a candidate-list overflow (a voxel with more than MFX_K3B_CAP triples within 1e-9 |y|^2 of its optimum): the
   // voxel-by-voxel path of solve_k3.hip (itself backed by the full scan), enqueued for EVERY slot of a batch and gated on the
   // device by the slot's overflow flag - no host read; an idle launch sequence costs ~25 us per voxel
-  StreamMem fG(st), fcol(st), fbs(st), fbt(st), fout(st), fk3(st);
-  SolveArgs fa{};
-  for (int q = 0; q < 3; ++q) { fa.sizes[q] = N; fa.start[q] = (long)q * N; }
-  fa.M = M; fa.Kp = 3; fa.Ntot = LD; fa.lda = LD; fa.ntuples = (long)N * N * N;
-  fa.nblocks = (int)std::min<long>(16384, (fa.ntuples + 255) / 256);
-  HIPCHK(fG.alloc(sizeof(double) * (size_t)LD * LD));
-  HIPCHK(fcol.alloc(sizeof(double) * ((size_t)LD + 2)));
-  HIPCHK(fbs.alloc(sizeof(double) * (size_t)MFX_K3_CAP));
-  HIPCHK(fbt.alloc(sizeof(long) * (size_t)MFX_K3_CAP));
-  HIPCHK(fout.alloc(sizeof(double) * (MFX_GK + MFX_GK + 1 + (size_t)M)));
-  HIPCHK(fk3.alloc(k3_buf_bytes(N)));
-  fa.G = fG.as<double>(); fa.Aty = fcol.as<double>(); fa.ysq = fa.Aty + LD;
-  fa.blk_score = fbs.as<double>(); fa.blk_tuple = fbt.as<long>();
-  fa.w = fout.as<double>(); fa.sub = (long*)(fa.w + MFX_GK); fa.minobj = (double*)(fa.sub + MFX_GK); fa.yrec = fa.minobj + 1;
-  const K3Bufs fkb = k3_bufs(fk3.as<char>());
+  // (the sequences of a batch's voxels are independent: they go to FL internal streams side by side, each with its own
+  // buffers, between a fork behind the batch's last kernel and a join in front of the next batch's first)
+  constexpr int FL = 4;
+  if (int rc = lanes_setup(p->t->device)) return rc;
+  MfxThread& TT = mfx_thread();
+  const int nfl = std::min(FL, BT);
+  struct FSet {
+    StreamMem fG, fcol, fbs, fbt, fout, fk3;
+    explicit FSet(hipStream_t s) : fG(s), fcol(s), fbs(s), fbt(s), fout(s), fk3(s) {}
+  };
+  FSet fs0(st), fs1(st), fs2(st), fs3(st);   // allocated and released in the order of the caller's stream
+  FSet* fsets[FL] = {&fs0, &fs1, &fs2, &fs3};
+  SolveArgs fav[FL];
+  K3Bufs fkbv[FL];
+  for (int l = 0; l < nfl; ++l) {
+    SolveArgs fa{};
+    for (int q = 0; q < 3; ++q) { fa.sizes[q] = N; fa.start[q] = (long)q * N; }
+    fa.M = M; fa.Kp = 3; fa.Ntot = LD; fa.lda = LD; fa.ntuples = (long)N * N * N;
+    fa.nblocks = (int)std::min<long>(16384, (fa.ntuples + 255) / 256);
+    FSet& S = *fsets[l];
+    HIPCHK(S.fG.alloc(sizeof(double) * (size_t)LD * LD));
+    HIPCHK(S.fcol.alloc(sizeof(double) * ((size_t)LD + 2)));
+    HIPCHK(S.fbs.alloc(sizeof(double) * (size_t)MFX_K3_CAP));
+    HIPCHK(S.fbt.alloc(sizeof(long) * (size_t)MFX_K3_CAP));
+    HIPCHK(S.fout.alloc(sizeof(double) * (MFX_GK + MFX_GK + 1 + (size_t)M)));
+    HIPCHK(S.fk3.alloc(k3_buf_bytes(N)));
+    fa.G = S.fG.as<double>(); fa.Aty = S.fcol.as<double>(); fa.ysq = fa.Aty + LD;
+    fa.blk_score = S.fbs.as<double>(); fa.blk_tuple = S.fbt.as<long>();
+    fa.w = S.fout.as<double>(); fa.sub = (long*)(fa.w + MFX_GK); fa.minobj = (double*)(fa.sub + MFX_GK); fa.yrec = fa.minobj + 1;
+    fav[l] = fa;
+    fkbv[l] = k3_bufs(S.fk3.as<char>());
+  }
   if (int rc = mfx_prof_begin(st)) return rc;
   for (int q0 = 0; q0 < nvox; q0 += BT) {
     const int B = std::min(BT, nvox - q0);
@@ -798,25 +829,39 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
     hipLaunchKernelGGL(mfx_k3b_stats_kernel, dim3((LD + 255) / 256, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_gram_kernel, dim3((N + 63) / 64, (N + 127) / 128, 3 * B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_items_kernel, dim3((unsigned)(((size_t)N * nblk3 * MFX_K3M_KB + 255) / 256), 2, B), dim3(256), 0, st, k);
-    hipLaunchKernelGGL(mfx_k3b_pairs_kernel, dim3(256, B), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(mfx_k3b_pairs_kernel, dim3((N + 7) / 8, 3, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_greedy_kernel, dim3(3, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_screen_kernel, dim3((N + MFX_K3M_TJ * 32 - 1) / (MFX_K3M_TJ * 32), (N + MFX_K3M_TI * 32 - 1) / (MFX_K3M_TI * 32), B),
                        dim3(MFX_K3M_TI * 64), lds, st, k);
     hipLaunchKernelGGL(mfx_k3b_finalize_kernel, dim3(MFX_K3B_FW, B), dim3(256), 0, st, k);
     hipLaunchKernelGGL(mfx_k3b_finish_kernel, dim3(B), dim3(256), 0, st, k, pk, d_params, num_params);
     HIPCHK(hipGetLastError());
-    for (int b = 0; b < B; ++b) {   // gated fallback (see above)
+    // gated fallback (see above): fork, the slots dealt to the lanes, join
+    HIPCHK(hipEventRecord(TT.ev_lane[4], st));
+    const int nl = std::min(nfl, B);
+    int rc_fb = MFX_OK;
+    for (int l = 0; l < nl; ++l) HIPCHK(hipStreamWaitEvent(TT.s_lane[l], TT.ev_lane[4], 0));
+    for (int b = 0; b < B && rc_fb == MFX_OK; ++b) {
+      const int l = b % nl;
       const long v = h_list ? h_list[q0 + b] : q0 + b;
+      SolveArgs& fa = fav[l];
       fa.A = dA.as<double>() + (size_t)b * M * LD;
       fa.y = d_Y + (size_t)v * M;
       fa.run_if = k.ncand + 2 * b + 1;
-      if (int rc = launch_solver(fa, &fkb, st)) return rc;
+      rc_fb = launch_solver(fa, &fkbv[l], TT.s_lane[l]);
+      if (rc_fb != MFX_OK) break;
       PackArgs pa = pk;
       pa.run_if = fa.run_if;
       pa.w = fa.w; pa.sub = fa.sub; pa.minobj = fa.minobj; pa.yrec = fa.yrec; pa.y = fa.y;
       pa.out = d_params + (size_t)v * num_params;
-      hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, st, pa);
+      hipLaunchKernelGGL(mfx_pack_params_kernel, dim3(1), dim3(64), 0, TT.s_lane[l], pa);
     }
+    for (int l = 0; l < nl; ++l) {   // (also on the error path: the buffers are released in the order of `st`)
+      const hipError_t e1 = hipEventRecord(TT.ev_lane[l], TT.s_lane[l]);
+      const hipError_t e2 = hipStreamWaitEvent(st, TT.ev_lane[l], 0);
+      if ((e1 != hipSuccess || e2 != hipSuccess) && rc_fb == MFX_OK) rc_fb = fail(MFX_ERR_HIP, "stream join failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+    if (rc_fb != MFX_OK) return rc_fb;
     HIPCHK(hipGetLastError());
     if (k3dbg) {   // developer diagnostics: synchronises
       std::vector<unsigned long long> h(4 * (size_t)B + 0), ht(B);
@@ -864,13 +909,7 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   // of dictionary, 16 MB of candidate list per set)
   constexpr int LANES = 2;   // (3: no further gain, 4: slower - measured at config 5)
   MfxThread& T = mfx_thread();
-  if (T.lane_device != p->t->device) {
-    for (int l = 0; l < LANES; ++l) { if (T.s_lane[l]) (void)hipStreamDestroy(T.s_lane[l]); T.s_lane[l] = nullptr; }
-    for (int l = 0; l < 3; ++l) { if (T.ev_lane[l]) (void)hipEventDestroy(T.ev_lane[l]); T.ev_lane[l] = nullptr; }
-    for (int l = 0; l < LANES; ++l) HIPCHK(hipStreamCreateWithFlags(&T.s_lane[l], hipStreamNonBlocking));
-    for (int l = 0; l < 3; ++l) HIPCHK(hipEventCreateWithFlags(&T.ev_lane[l], hipEventDisableTiming));
-    T.lane_device = p->t->device;
-  }
+  if (int rc = lanes_setup(p->t->device)) return rc;
   const int nl = std::min(nvox, LANES);
   struct Set {
     StreamMem dA, dG, dAty, dysq, dbs, dbt, dw, dsub, dobj, dyrec, dk3;
@@ -906,8 +945,8 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   if (int rc = mfx_prof_begin(st)) return rc;
   hipStream_t ls[LANES] = {st, st};
   if (nl > 1) {   // fork
-    HIPCHK(hipEventRecord(T.ev_lane[2], st));
-    for (int l = 0; l < nl; ++l) { ls[l] = T.s_lane[l]; HIPCHK(hipStreamWaitEvent(ls[l], T.ev_lane[2], 0)); }
+    HIPCHK(hipEventRecord(T.ev_lane[4], st));
+    for (int l = 0; l < nl; ++l) { ls[l] = T.s_lane[l]; HIPCHK(hipStreamWaitEvent(ls[l], T.ev_lane[4], 0)); }
   }
   int rc_loop = MFX_OK;
   for (int q = 0; q < nvox && rc_loop == MFX_OK; ++q) {

@@ -70,8 +70,8 @@ struct MfxThread {
   };
   std::vector<Arena> arenas;
   unsigned long long arena_clock = 0;
-  hipStream_t s_lane[2] = {nullptr, nullptr};
-  hipEvent_t ev_lane[3] = {nullptr, nullptr, nullptr};   // [lane] join, [2] fork
+  hipStream_t s_lane[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_lane[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [lane] join, [4] fork
   int lane_device = -1;
 };
 
