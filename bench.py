@@ -496,7 +496,7 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
     out["c5"] = {"workload": "C5: %d voxels, 3 fascicles, sub-dictionaries [%d, %d, %d], %d measurements (%.2e triples per voxel), explicit rotate_atom plan"
                              % (C5_V, C5_N, C5_N, C5_N, sch5.shape[0], float(C5_N) ** 3),
                  "value": round(C5_V / dt, 1), "unit": "voxels/s", "ms_per_voxel": round(dt / C5_V * 1e3, 3),
-                 "kernel": "mfx_k3b_screen_kernel (+ mfx_k3b_gram_kernel, mfx_k3b_items_kernel, mfx_k3b_finalize_kernel), batches of 16 voxels", "bound": "valu issue",
+                 "kernel": "mfx_k3b_screen_kernel (+ mfx_k3b_gram_kernel, mfx_k3b_items_kernel, mfx_k3b_finalize_kernel), batches of 32 voxels", "bound": "valu issue",
                  "reference_flop_per_voxel": FLOP_PER_VOXEL_C5, "reference_TFLOPs_equivalent": round(ach, 2),
                  "reference_TFLOPs_is": "the REFERENCE's work (three cross-Grams + N^3 three-column solves of ~40 flop) per second; the "
                                         "screen decides 1024 triples with one FP16 MFMA and ~47 vector instructions (36 of them building its operands), so this is NOT a utilisation",

@@ -41,10 +41,10 @@ typedef float k3_f16v __attribute__((ext_vector_type(16)));
 #define MFX_K3B_CAP (1 << 22)      // candidate list entries per voxel
 #define MFX_K3M_KB 4               // i3 values per operand block
 #ifndef MFX_K3M_TI
-#define MFX_K3M_TI 4               // i1 tiles of 32 per workgroup (one per wave)
+#define MFX_K3M_TI 8               // i1 tiles of 32 per workgroup (one per wave)
 #endif
 #ifndef MFX_K3M_TJ
-#define MFX_K3M_TJ 2               // i2 tiles of 32 per workgroup (each wave multiplies all of them)
+#define MFX_K3M_TJ 4               // i2 tiles of 32 per workgroup (each wave multiplies all of them)
 #endif
 #ifndef MFX_K3M_Q
 #define MFX_K3M_Q 1024             // queue entries per block parity
@@ -316,14 +316,14 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
   if (tid == 0) s_T[0] = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;
   if (k.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) k.dbg[4 * b + 3] = *thrp;
   __syncthreads();
-  // accumulator inputs of this wave's four tile pairs: -a12 + margin |d1||d2|, rounded up; -1e30 where there is no pair
-  // Beside it a12 itself (FP32) for the second test of tiles with a hit (below): the relaxed score in FP32 without the
+  // accumulator inputs of this wave's TJ tile pairs: -a12 + margin |d1||d2|, rounded up; -1e30 where there is no pair.
+  // Tiles with a hit get a second test (below): the relaxed score in FP32 without the
   // matrix-pipe margin, and the sign of the third atom's weight in the relaxed optimum - the relaxation lets it go negative,
   // and a triple whose relaxed optimum gives atom 3 a CLEARLY negative weight has its NNLS optimum on a face: {1, 3}, {2, 3},
   // {3} stay below the threshold unless an "always pass" slot fired (accumulator ~1e9: kept), the pair {1, 2}'s own score
   // reaches it only for pairs marked here (accumulator input 3e9: every third atom kept).  In a voxel with a flat optimum
   // (an inactive atom) the first test alone lets 1e7 .. 3e8 triples through at N = 1500.
-  k3_f16v C[TJ], A12[TJ];
+  k3_f16v C[TJ];
   {
     const double T0 = __longlong_as_double((long long)*(volatile unsigned long long*)thrp) - eps_abs;   // (the threshold only rises)
 #pragma unroll
@@ -332,15 +332,14 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int il = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh, i = i0 + il;
-        float c = -1e30f, a12f = 0.0f;
+        float c = -1e30f;
         if (i < N && j < N) {
           const double a11 = s_aa[il], a22 = s_aa[TI * 32 + jl], a12 = G12[(size_t)i * N + j], y1 = s_ay[il], y2 = s_ay[TI * 32 + jl];
           const double v = fma(MFX_K3M_C, sqrt(a11 * a22), -a12);
           c = (float)(v + fabs(v) * 1.3e-7);
           if (score2(a11, a12, a22, y1, y2) >= T0) c = 3e9f;
-          a12f = (float)a12;
         }
-        C[t][g] = c; A12[t][g] = a12f;
+        C[t][g] = c;
       }
     }
   }
@@ -551,7 +550,10 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
                 if (it1.y > 0.0f && it2.y > 0.0f) {
                   // everything multiplied through by N12 = |d1'||d2'| (no division): c' = a / N12, a = a12 - u1 u2;
                   // E_i = e_i N12, DEN = (1 - c'^2) N12^2, NUM = num N12
-                  const float n12 = it1.y * it2.y, av = fmaf(-u1f, u2f, A12[t][g]);
+                  // (a12 itself comes from the Gram in memory: this path is rare, and a register copy of the tile per column
+                  // tile is what kept the workgroup at 128 x 64 pairs)
+                  const float a12f = (float)G12[(size_t)(i0 + ilr) * N + (j0 + t * 32 + lr)];
+                  const float n12 = it1.y * it2.y, av = fmaf(-u1f, u2f, a12f);
                   const float E1 = fmaf(it1.x, n12, -av * it2.x), E2 = fmaf(it2.x, n12, -av * it1.x);
                   const float DEN = fmaf(n12, n12, -av * av), NUM = fmaf(it2.x, E2, it1.x * E1);
                   const float zt = 3e-6f * n12 * (fabsf(it1.x) + fabsf(it2.x));

@@ -738,7 +738,7 @@ static int lanes_setup(int device) {
 }
 
 // Three fascicles without extra columns (BASELINE config 5) in batches of voxels: fit_k3.hip.  Everything is enqueued on `st`.
-#define MFX_K3B_BATCH 16
+#define MFX_K3B_BATCH 32
 static bool k3b_applies(int K, int NX, int N, long ntuples) { return K == 3 && NX == 0 && N >= 32 && ntuples >= (1L << 18); }
 static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_peaks, int peaks_ld, const int* h_list, int nvox,
                           int maxfasc, int csf_on, int ear_on, double* d_params, hipStream_t st) {
