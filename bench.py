@@ -499,7 +499,7 @@ def extra_measurements(plan, ms, sch, d_Y, d_peaks, peaks_h, d_out, V, N, M, dev
                  "kernel": "mfx_k3b_screen_kernel (+ mfx_k3b_gram_kernel, mfx_k3b_items_kernel, mfx_k3b_finalize_kernel), batches of 32 voxels", "bound": "valu issue",
                  "reference_flop_per_voxel": FLOP_PER_VOXEL_C5, "reference_TFLOPs_equivalent": round(ach, 2),
                  "reference_TFLOPs_is": "the REFERENCE's work (three cross-Grams + N^3 three-column solves of ~40 flop) per second; the "
-                                        "screen decides 1024 triples with one FP16 MFMA and ~47 vector instructions (36 of them building its operands), so this is NOT a utilisation",
+                                        "screen decides 1024 triples with one FP16 MFMA and ~25 vector instructions (most of them building its operands), so this is NOT a utilisation",
                  "issue_utilisation_pmc": _pmc_field(PMC_C5, "issue_utilisation"), "mfma_pipe_utilisation_pmc": _pmc_field(PMC_C5, "mfma_pipe_utilisation"),
                  "pmc_from": PMC_C5 if os.path.exists(os.path.join(ROOT, PMC_C5)) else None}
     del plan5, rt5, d_Y5, d_pk5, o5

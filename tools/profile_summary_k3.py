@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense tools/profile_run_k3.sh's rocprofv3 outputs (gpurun_out/p3_*) into profiles/r03_kernel_stats_k3.csv and
-profiles/r03_pmc_k3_screen.json (the triple screen of fit_k3.hip: 2 calls x 2 batches of 8 voxels at 1500 atoms x 300 rows)."""
+profiles/r03_pmc_k3_screen.json (the triple screen of fit_k3.hip: 2 calls x 1 batch of 32 voxels at 1500 atoms x 300 rows)."""
 import collections, csv, glob, json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def newest(pat):
@@ -22,9 +22,9 @@ for d in glob.glob(R + '/gpurun_out/p3_pmc_*/runc'):
     for r in csv.DictReader(open(f)):
         if 'mfx_k3b_screen_kernel' in r['Kernel_Name']:
             res[r['Counter_Name']] += float(r['Counter_Value'])
-V = 2 * 16      # two timed calls of 16 voxels
+V = 2 * 32      # two timed calls of 32 voxels (one batch each)
 cyc = res.get('GRBM_GUI_ACTIVE', 0) / 8
-out = {"round": 3, "command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/dev_time_c5.py 1500 (MFX_DEV_V=16), one pass per counter group",
+out = {"round": 3, "command": "rocprofv3 --pmc <C> --kernel-trace -- python3 tools/dev_time_c5.py 1500 (MFX_DEV_V=32), one pass per counter group",
        "kernel": "mfx_k3b_screen_kernel", "voxels_counted": V, "triples_per_voxel": 1500.0 ** 3, "counters": dict(res),
        "valu_insts_per_voxel": res.get('SQ_INSTS_VALU', 0) / V, "mfma_insts_per_voxel": res.get('SQ_INSTS_MFMA', 0) / V,
        "lds_insts_per_voxel": res.get('SQ_INSTS_LDS', 0) / V, "vmem_read_insts_per_voxel": res.get('SQ_INSTS_VMEM_RD', 0) / V,
