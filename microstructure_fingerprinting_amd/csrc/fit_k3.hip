@@ -511,12 +511,15 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
     if (blk < nblk) {
 #endif
       const int nk = min(KB, N - k0);
-      for (int kk = 0; kk < nk; ++kk) {
-        const k3_h8 af = sA[(size_t)(buf * KB + kk) * SA + wave * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < TJ; ++t) {
-          const k3_h8 bf = sB[(size_t)(buf * KB + kk) * SB + t * 64 + lane];
-          const k3_f16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, C[t], 0, 0, 0);
+      // One multiplication ahead: the matrix instruction of the NEXT (third atom, column tile) is issued before the result
+      // of the current one is looked at, so its 8 passes run behind these ~10 vector instructions instead of in front of them.
+      auto mma = [&](const k3_h8& af, int kk, auto tc) -> k3_f16v {
+        constexpr int t = decltype(tc)::value;
+        const k3_h8 bf = sB[(size_t)(buf * KB + kk) * SB + t * 64 + lane];
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, C[t], 0, 0, 0);
+      };
+      auto post = [&](const k3_f16v& d, int kk, auto tc) {
+        constexpr int t = decltype(tc)::value;
           // any test value >= 0 in the tile?  As signed integers the bit patterns of non-negative floats are the non-negative
           // ones: an integer maximum (three operands per instruction, no NaN handling) answers it.  (-0.0 counts as negative:
           // it would take an accumulator input of exactly -0, and that one carries a positive margin.)
@@ -579,7 +582,24 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
               }
             }
           }
-        }
+      };
+      k3_h8 af = sA[(size_t)(buf * KB) * SA + wave * 64 + lane];
+      k3_f16v dcur = mma(af, 0, std::integral_constant<int, 0>{});
+      for (int kk = 0; kk < nk; ++kk) {
+        mfx_static_for<0, TJ>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          k3_f16v dnext = dcur;
+          if constexpr (t + 1 < TJ) {
+            dnext = mma(af, kk, std::integral_constant<int, t + 1>{});
+          } else {
+            if (kk + 1 < nk) {
+              af = sA[(size_t)(buf * KB + kk + 1) * SA + wave * 64 + lane];
+              dnext = mma(af, kk + 1, std::integral_constant<int, 0>{});
+            }
+          }
+          post(dcur, kk, tc);
+          dcur = dnext;
+        });
       }
     }
     // the next block's items and third-atom constant are first touched here, behind the multiplications: the wait for
