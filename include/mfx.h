@@ -55,7 +55,7 @@ typedef struct mfx_plan mfx_plan;     /* device-resident per-protocol row plan  
 const char* mfx_last_error(void);
 int mfx_device_count(void);
 /* library/ABI version, bumped on any signature change or new entry point (3: mfx_fit_batch_volume, counters 8-10 of
- * mfx_debug_last_counter, mfx_debug_set_k3_cap, mfx_debug_set_force_generic) */
+ * mfx_debug_last_counter, mfx_debug_set_k3_cap, mfx_debug_set_force_generic, mfx_debug_set_k3_screen) */
 int mfx_abi_version(void);
 
 /* ---- tables: replaces the interpolator objects returned by
@@ -213,6 +213,10 @@ void mfx_debug_set_k3_cap(int cap);
  * through the explicit-dictionary solver, the path shapes beyond the fused kernels' limits take by themselves (dictionaries
  * or protocols too large for the LDS, more than 16 CSF+EAR columns); tests use it to check that path on small shapes. */
 void mfx_debug_set_force_generic(int enabled);
+/* Diagnostic: 0 sends problems with three sub-dictionaries (mfx_fit_batch* with three fascicles, mfx_solve_exhaustive) through
+ * the plain scan - one thread per index triple, every triple scored, no batched path and no relaxed-bound screen - the
+ * unscreened referee of the full-size three-fascicle test (about 40 ms per voxel at 1 500 atoms). */
+void mfx_debug_set_k3_screen(int enabled);
 /* Diagnostic: 0 routes two-fascicle voxels to the FP64 kernel only (same as MFX_K2_SCREEN=0 in the environment). */
 void mfx_debug_set_k2_screen(int enabled);
 /* Diagnostic: 1 routes two-fascicle voxels of protocols with 129..256 measurements to the wide (one wave per SIMD)

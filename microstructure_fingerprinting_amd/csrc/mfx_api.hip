@@ -222,6 +222,7 @@ extern "C" void mfx_debug_set_k2_maxc(int maxc) { mfx_thread().k2_maxc = (maxc <
 extern "C" void mfx_debug_set_k2x_maxc(int maxc) { mfx_thread().k2x_maxc = (maxc < 0 || maxc > MFX_XMAXC) ? MFX_XMAXC : maxc; }
 extern "C" void mfx_debug_set_k3_cap(int cap) { mfx_thread().k3_cap = cap > 0 ? cap : 0; }
 extern "C" void mfx_debug_set_force_generic(int enabled) { mfx_thread().force_generic = enabled ? 1 : 0; }
+extern "C" void mfx_debug_set_k3_screen(int enabled) { mfx_thread().k3_screen = enabled ? 1 : 0; }
 extern "C" void mfx_debug_set_k2s_images(int nb) { mfx_thread().k2s_nb = (nb == 2) ? 2 : 0; }
 extern "C" void mfx_debug_set_k2s_cap(int cap) {
   int c = 4;
@@ -683,7 +684,7 @@ static int fit_class_fused(const mfx_plan* p, const double* d_Y, const double* d
   if (K == 3) {
     MfxThread& T = mfx_thread();
     if (T.k3_batch < 0) { const char* e = getenv("MFX_K3_BATCH"); T.k3_batch = (e && e[0] == '0') ? 0 : 1; }
-    if (T.k3_batch && k3b_applies(K, X.d.NX, p->t->d.N, (long)p->t->d.N * p->t->d.N * p->t->d.N))
+    if (T.k3_batch && T.k3_screen && k3b_applies(K, X.d.NX, p->t->d.N, (long)p->t->d.N * p->t->d.N * p->t->d.N))
       return fit_k3_batched(p, d_Y, d_peaks, peaks_ld, h_list, nvox, maxfasc, csf_on, ear_on, d_params, st);
     return fit_class_generic(p, d_Y, d_peaks, peaks_ld, h_list, nvox, K, X, maxfasc, csf_on, ear_on, d_params, st);
   }
@@ -903,7 +904,7 @@ static int fit_class_generic(const mfx_plan* p, const double* d_Y, const double*
   }
   a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
   a.nblocks = (int)std::min<long>(16384, (ntup + 255) / 256);
-  const bool k3 = k3_applies(a);
+  const bool k3 = mfx_thread().k3_screen && k3_applies(a);
   const size_t nlist = k3 ? (size_t)MFX_K3_CAP : (size_t)a.nblocks;
   // two voxels in flight on two internal streams, each with its own set of buffers (at config 5: 162 MB of Gram, 11 MB
   // of dictionary, 16 MB of candidate list per set)
@@ -1463,7 +1464,7 @@ extern "C" int mfx_solve_exhaustive(const double* A, int64_t lda, int M, const i
   if (Ntot > 30000) return fail(MFX_ERR_UNSUPPORTED, "explicit solver supports up to 30000 columns (got %ld)", Ntot);
   a.M = M; a.Kp = Kp; a.Ntot = (int)Ntot; a.lda = Ntot; a.ntuples = ntup;
   a.nblocks = (int)std::min<long>(8192, (ntup + 255) / 256);
-  const bool k3 = k3_applies(a);
+  const bool k3 = mfx_thread().k3_screen && k3_applies(a);
   const size_t nlist = k3 ? (size_t)MFX_K3_CAP : (size_t)a.nblocks;
   std::vector<double> Ac((size_t)M * Ntot);
   for (int k = 0; k < M; ++k) std::memcpy(&Ac[(size_t)k * Ntot], A + (size_t)k * lda, sizeof(double) * Ntot);

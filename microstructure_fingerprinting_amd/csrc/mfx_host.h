@@ -33,6 +33,7 @@ struct MfxThread {
   int k2s_nb = 0;          // 0: as many chunk images as fit; 2: force the two-image schedule
   int k2s_cap = 0;         // 0: MFX_S_CAP
   int force_generic = 0;   // 1: every voxel class through the explicit-dictionary solver (tests of the out-of-limits fallback)
+  int k3_screen = 1;       // 0: three sub-dictionaries through the plain one-thread-per-tuple scan (no batched path, no relaxed-bound screen: the referee of the full-size test)
   int k3_cap = 0;          // > 0: candidate-list entries of the batched three-fascicle path (tests force the overflow fallback)
   int k3_batch = -1;       // MFX_K3_BATCH=0: three-fascicle voxels one by one through solve_k3.hip (no batched fit_k3.hip path)
   int k2_screen = -1;      // MFX_K2_SCREEN=0 disables the screening kernels

@@ -844,6 +844,51 @@ def test_c5_full_size_properties():
                         assert res <= objective(v, alt)[0] * (1 + 1e-12), (v, base, k, dlt)
 
 
+def test_c5_full_size_screen_vs_unscreened_scan():
+    """BASELINE config 5 at its full size: the batched path (triple test on the matrix pipe, second test, candidate list)
+    against a scan of ALL 3.4e9 triples of every voxel with no screen at all (mfx_debug_set_k3_screen(0): one thread per
+    triple, every triple scored from the FP64 Gram, the same exact stage) - whether any screening stage pruned the global
+    optimum is exactly what this compares.  40 voxels: bench-style mixtures at SNR 30, four at SNR 10, two noise-free, four
+    whose signal holds only TWO fascicles (flat optimum: the third atom is inactive), two with ONE."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    import bench
+    rng = np.random.default_rng(77)
+    sch = synth.make_scheme(rng, 1, [1000, 2000, 3000, 4000], [75, 75, 75, 74])
+    N, M = 1500, sch.shape[0]
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    dev = torch.device("cuda", 0)
+    V = 40
+    _, dpk, dY = bench.synth_voxels(plan, V, N, M, dev, 11, K=3)
+    Y = dY.cpu().numpy()
+    clean = bench.synth_voxels(plan, V, N, M, dev, 11, K=3, snr=1e12)[2].cpu().numpy()
+    Y[28:32] = clean[28:32] + 3.0 * (Y[28:32] - clean[28:32])    # SNR 10
+    Y[32:34] = clean[32:34]                                      # noise-free
+
+    def atom(v, k, n):
+        return engine.rotate_columns_dev(plan, dpk[v:v + 1, 3 * k:3 * k + 3].contiguous(),
+                                         torch.tensor([n], dtype=torch.int32, device=dev)).cpu().numpy()[0]
+    for v in range(34, 38):                                      # two fascicles only (flat optimum: the third atom is inactive)
+        Y[v] = 300.0 * atom(v, 0, 17 + v) + 200.0 * atom(v, (v % 2) + 1, 1203 - v) + rng.normal(0, 500.0 / 30.0, M)
+    for v in range(38, 40):                                      # one fascicle only
+        Y[v] = 500.0 * atom(v, v % 3, 700 + v) + rng.normal(0, 500.0 / 30.0, M)
+    dY = torch.from_numpy(Y).to(dev)
+    got = engine.fit_batch_dev(plan, dY, dpk, 3).cpu().numpy()
+    lib = L.lib()
+    lib.mfx_debug_set_k3_screen(0)
+    try:
+        ref = engine.fit_batch_dev(plan, dY, dpk, 3).cpu().numpy()
+    finally:
+        lib.mfx_debug_set_k3_screen(1)
+    assert np.array_equal(got[:, 4:7], ref[:, 4:7]), (got[:, 4:7], ref[:, 4:7])
+    assert np.array_equal(got, ref)
+    assert np.all(got[:, 0] > 0)
+
+
 def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     """[782, 782, 1] (two fascicles + CSF) at BASELINE config 2's size through the screening pipeline (split-FP16 screening
     kernel with the CSF column projected out -> per-voxel short lists -> exact stage in list mode -> plain kernel for the
