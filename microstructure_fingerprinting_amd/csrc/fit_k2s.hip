@@ -516,7 +516,10 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
     };
     // the item's interpolation offsets are the same for every chunk of the round: registers, not LDS
     // (not for KS = 16: its A tile takes 128 registers and every further one spills)
-    constexpr bool GT = KS <= 13;
+#ifndef MFX_XC_GT
+#define MFX_XC_GT 0   // (the CSF form needs the registers: with the offsets in registers it spilled 26-29, 11 scratch accesses per period)
+#endif
+    constexpr bool GT = KS <= 13 && (!XC || MFX_XC_GT);
     float g_t[GT ? 8 : 1];
     if constexpr (GT) {
 #pragma unroll
