@@ -229,11 +229,24 @@ def main(a=None):
     if world > 1 and backend == "nccl" and ndev < world:
         sys.stderr.write("bench.py: %d ranks but only %d visible GPU(s): one process per GPU, no sharing\n" % (world, ndev))
         sys.exit(3)
+    # MFX_BENCH_FORCE_DIST=1: a one-rank group goes through the same process-group calls as N ranks (rehearsal of the RCCL
+    # path on a one-GPU box, under torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or os.environ.get("MFX_BENCH_FORCE_DIST") == "1"
     dev_index = (local_rank % ndev) if world > 1 else 0
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    if world > 1:
+    json_fd = None
+    if use_dist:
+        # RCCL prints a version banner on STDOUT when the first communicator is made (seen on the GPU box: five lines in
+        # front of the result).  The contract is ONE JSON line on stdout: everything else this process and its libraries
+        # print goes to stderr, the line itself is written to the saved descriptor.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -243,7 +256,7 @@ def main(a=None):
     ms = sch = None
     if rank == 0:
         sch, dic, ms = build_model(a.atoms)
-    if world > 1:
+    if use_dist:
         from microstructure_fingerprinting_amd import dist as mdist
         ms, sch = mdist.broadcast_interpolator(ms, sch, src=0, device=dev if backend == "nccl" else None)
     ms.device = dev.index or 0
@@ -272,7 +285,7 @@ def main(a=None):
     # ---- timed region: barrier + sync on both sides; HIP events on the launch stream for the kernel
     lib.mfx_set_profiling(1)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     kern_ms = []
@@ -282,14 +295,14 @@ def main(a=None):
         # for that launch only (the next launch is queued right after)
         kern_ms.append(lib.mfx_last_kernel_ms())
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     lib.mfx_set_profiling(0)
     L.check(lib.mfx_plan_status(plan.handle(), stream.cuda_stream))
     elapsed = t1 - t0
     ranks_seen, vox_per_rank, dev_per_rank = 1, [V], [torch.cuda.get_device_name(dev)]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -388,13 +401,17 @@ def main(a=None):
                "config": {"workload": "C2: %d voxels%s, 2 fascicles, %d atoms x %d measurements"
                                       % (a.voxels, "/GPU" if a.scaling == "weak" else " in total", N, M),
                           "voxels_per_gpu": global_V // world, "global_voxels": global_V, "atoms": N, "measurements": M,
-                          "ranks_in_group": ranks_seen, "backend": backend if world > 1 else None,
+                          "ranks_in_group": ranks_seen, "backend": backend if use_dist else None,
                           "voxels_per_rank": vox_per_rank, "device_per_rank": dev_per_rank,
                           "sharding": "voxel shards, no data-path collective; dictionary broadcast once over RCCL"},
                "roofline": roof, "cpu_baseline": cpu}
         res.update(extras)
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(res) + "\n").encode())
+        else:
+            print(json.dumps(res), flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return res
