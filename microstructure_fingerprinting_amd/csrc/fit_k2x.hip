@@ -815,11 +815,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
   long key = -1;
   // one tuple (i, j, t) exactly: _3 = Cramer test + explicit residual (mf_utils.py:554-593), _4up = active-set optimum
   // from a sequentially summed Gram + explicit residual (mf_utils.py:640-649); keeps the lexicographic (res, scan key) minimum
-  auto consider = [&](int i, int j, int t) -> double {
+  // (col1(m), col2(m): the rotated atoms' entries - through the table, or from columns staged in LDS)
+  auto consider_cols = [&](int i, int j, int t, auto&& col1, auto&& col2) -> double {
     const int c3 = (Kp == 3) ? t : 0, c4 = 1 + t;
     double a11 = 0.0, a22 = 0.0, a12 = 0.0, y1 = 0.0, y2 = 0.0, a13 = 0.0, a23 = 0.0, a14 = 0.0, a24 = 0.0;
     for (int m = 0; m < M; ++m) {
-      const double d1 = elem(0, m, i), d2 = elem(1, m, j), ym = s_y[m];
+      const double d1 = col1(m), d2 = col2(m), ym = s_y[m];
       const double x3 = xx[(size_t)m * NX + c3];
       a11 += d1 * d1; a22 += d2 * d2; a12 += d1 * d2; y1 += ym * d1; y2 += ym * d2;
       a13 += d1 * x3; a23 += d2 * x3;
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       auto explicit_res = [&](const double* ww) {
         double rr = 0.0;
         for (int m = 0; m < M; ++m) {
-          const double tt = (ww[0] * elem(0, m, i) + ww[1] * elem(1, m, j) + ww[2] * xx[(size_t)m * NX + c3] - s_y[m]);
+          const double tt = (ww[0] * col1(m) + ww[1] * col2(m) + ww[2] * xx[(size_t)m * NX + c3] - s_y[m]);
           rr += tt * tt;
         }
         return rr;
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
       nnls_gram_subsets(4, g, yy, u);
       double rr = 0.0;
       for (int m = 0; m < M; ++m) {
-        const double tt = (u[0] * elem(0, m, i) + u[1] * elem(1, m, j) + u[2] * xx[(size_t)m * NX] + u[3] * xx[(size_t)m * NX + c4] - s_y[m]);
+        const double tt = (u[0] * col1(m) + u[1] * col2(m) + u[2] * xx[(size_t)m * NX] + u[3] * xx[(size_t)m * NX + c4] - s_y[m]);
         rr += tt * tt;
       }
       r = rr;
@@ -852,6 +853,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
     }
     if (r < res || (r == res && k < key)) { res = r; key = k; w[0] = u[0]; w[1] = u[1]; w[2] = u[2]; w[3] = u[3]; }
     return r;
+  };
+  auto consider = [&](int i, int j, int t) -> double {
+    return consider_cols(i, j, t, [&](int m) { return elem(0, m, i); }, [&](int m) { return elem(1, m, j); });
   };
   if constexpr (LIST) {
     // ---- list mode: the screening kernel's short list stands for the pair scan.  Every listed pair through the
@@ -1012,10 +1016,42 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
         }
       }
       __syncthreads();
-      for (int q = tid; q < NW * WCAP * ntup; q += WG) {
-        const int c = q / ntup, t = q - c * ntup;
-        const int w = c / WCAP, k = c - w * WCAP;
-        if (k < s_qn[2 * w] && s_cand[c].score >= thr_final) consider(s_cand[c].i, s_cand[c].j, t);
+      // A thread that walks its tuple's 2 x M rows through the table alone pays an L2 round trip per row block, twice (Gram
+      // scalars, explicit residual): 370 k of a config-4 voxel's cycles.  Instead, per batch of PB listed pairs the whole
+      // workgroup stages the two rotated columns of every pair in the (idle) chunk buffers and one thread per (pair, tuple)
+      // runs the reference's arithmetic on the staged columns - the same values in the same order.
+      constexpr int PB = NBUF * 8;          // pairs per batch: two columns of MP rows each
+      int* s_pl = (int*)s_a1x;              // [NW * WCAP] slots of the surviving pairs, compacted; [NW * WCAP]: their number
+      static_assert(NW * WCAP + 1 <= NW * 16 * MFX_XS * 2, "pair list in the row staging area");
+      if (wave == 0) {
+        int n = 0;
+        for (int c0 = 0; c0 < NW * WCAP; c0 += 64) {
+          const int c = c0 + lane, w = c / WCAP, k = c - w * WCAP;
+          const bool ok = c < NW * WCAP && k < s_qn[2 * w] && s_cand[c].score >= thr_final;
+          const unsigned long long mk = __ballot(ok);
+          if (ok) s_pl[n + __popcll(mk & ((1ull << lane) - 1ull))] = c;
+          n += __popcll(mk);
+        }
+        if (lane == 0) s_pl[NW * WCAP] = n;
+      }
+      __syncthreads();
+      const int npl = s_pl[NW * WCAP];
+      for (int c0 = 0; c0 < npl; c0 += PB) {
+        const int nb = min(PB, npl - c0);
+        for (int q = tid; q < nb * 2 * MP; q += WG) {
+          const int c = q / (2 * MP), r = q - c * (2 * MP), k = r / MP, m = r - k * MP;
+          const CandX e = s_cand[s_pl[c0 + c]];
+          sB[q] = (m < M) ? elem(k, m, k ? e.j : e.i) : 0.0;
+        }
+        __syncthreads();
+        for (int q = tid; q < nb * ntup; q += WG) {
+          const int c = q / ntup, t = q - c * ntup;
+          const CandX e = s_cand[s_pl[c0 + c]];
+          const double* d1s = sB + (size_t)c * (2 * MP);
+          const double* d2s = d1s + MP;
+          consider_cols(e.i, e.j, t, [&](int m) { return d1s[m]; }, [&](int m) { return d2s[m]; });
+        }
+        __syncthreads();   // the next batch overwrites the staged columns
       }
     }
     for (int f = 0; f < nfam_app; ++f) {   // workgroup-uniform loop
