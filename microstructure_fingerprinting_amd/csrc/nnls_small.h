@@ -142,13 +142,7 @@ __device__ inline void nnls_gram_subsets(int n, const double* g, const double* y
   auto G = [&](int p, int q) { if (p > q) { int t = p; p = q; q = t; } return g[p * n - p * (p - 1) / 2 + (q - p)]; };
   double best = 0.0;
   for (int k = 0; k < n; ++k) w[k] = 0.0;
-  // The support with all n columns goes first: if its unconstrained solution is non-negative it satisfies the KKT conditions
-  // of the whole problem - it IS the NNLS optimum (what Lawson-Hanson returns) - and the 2^n - 2 smaller supports need not be
-  // solved (they were: 15 eliminations with dynamically indexed scratch arrays per tuple, most of the exact stage's time in the
-  // four-column classes).  Otherwise every support is tried as before.
-  for (int pass = 0; pass < 2; ++pass)
-  for (int mask = pass ? 1 : (1 << n) - 1; mask < (1 << n); ++mask) {
-    if (pass && mask == (1 << n) - 1) break;          // (tried in pass 0)
+  for (int mask = 1; mask < (1 << n); ++mask) {
     int idx[4], c = 0;
     for (int k = 0; k < n; ++k) if (mask & (1 << k)) idx[c++] = k;
     // eliminate in an order that does not depend on where a column sits in the tuple (largest A'y first, as the
@@ -184,7 +178,6 @@ __device__ inline void nnls_gram_subsets(int n, const double* g, const double* y
       best = sc;
       for (int k = 0; k < n; ++k) w[k] = 0.0;
       for (int p = 0; p < c; ++p) w[idx[p]] = ws[p];
-      if (!pass) return;                              // the full support is feasible: optimal
     }
   }
 }
