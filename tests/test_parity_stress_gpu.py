@@ -889,6 +889,49 @@ def test_c5_full_size_screen_vs_unscreened_scan():
     assert np.all(got[:, 0] > 0)
 
 
+@pytest.mark.parametrize("N,dirs", [(64, [15, 15, 15, 15]), (100, [19, 19, 19, 19]), (257, [8, 8, 8, 8]), (130, [75, 75, 75, 74]), (513, [13, 12, 12, 12])])
+def test_three_fascicles_ragged_shapes_screen_vs_unscreened_scan(N, dirs):
+    """The batched three-fascicle path on shapes that are not multiples of its tiles (256 x 128 pairs per workgroup, blocks
+    of 4 third atoms, Gram tiles of 128 x 64 atoms and 16 measurement rows per group): dictionaries of 64 .. 513 atoms,
+    33 .. 300 measurements, 24 voxels each (mixtures, noise-free, one and two fascicles only) - against the unscreened scan
+    of all triples (mfx_debug_set_k3_screen(0)); rows must be identical."""
+    import torch
+    from microstructure_fingerprinting_amd import _lib as L
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    import bench
+    rng = np.random.default_rng(N)
+    sch = synth.make_scheme(rng, 1, [1000, 2000, 3000, 4000], dirs)
+    M = sch.shape[0]
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    dev = torch.device("cuda", 0)
+    V = 24
+    _, dpk, dY = bench.synth_voxels(plan, V, N, M, dev, 5, K=3)
+    Y = dY.cpu().numpy()
+    clean = bench.synth_voxels(plan, V, N, M, dev, 5, K=3, snr=1e12)[2].cpu().numpy()
+    Y[16:18] = clean[16:18]
+
+    def atom(v, k, n):
+        return engine.rotate_columns_dev(plan, dpk[v:v + 1, 3 * k:3 * k + 3].contiguous(),
+                                         torch.tensor([n], dtype=torch.int32, device=dev)).cpu().numpy()[0]
+    for v in range(18, 22):
+        Y[v] = 300.0 * atom(v, 0, (7 * v) % N) + 200.0 * atom(v, (v % 2) + 1, N - 1 - v) + rng.normal(0, 500.0 / 30.0, M)
+    for v in range(22, 24):
+        Y[v] = 500.0 * atom(v, v % 3, (11 * v) % N) + rng.normal(0, 500.0 / 30.0, M)
+    dY = torch.from_numpy(Y).to(dev)
+    got = engine.fit_batch_dev(plan, dY, dpk, 3).cpu().numpy()
+    lib = L.lib()
+    lib.mfx_debug_set_k3_screen(0)
+    try:
+        ref = engine.fit_batch_dev(plan, dY, dpk, 3).cpu().numpy()
+    finally:
+        lib.mfx_debug_set_k3_screen(1)
+    assert np.array_equal(got[:, 4:7], ref[:, 4:7]), (got[:, 4:7], ref[:, 4:7])
+    assert np.array_equal(got, ref)
+
+
 def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     """[782, 782, 1] (two fascicles + CSF) at BASELINE config 2's size through the screening pipeline (split-FP16 screening
     kernel with the CSF column projected out -> per-voxel short lists -> exact stage in list mode -> plain kernel for the
