@@ -288,9 +288,7 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
   k3_h8* sB = sA + 2 * KB * SA;                            // [2][KB][SB]
   double* s_aa = (double*)(sB + 2 * KB * SB);              // [(TI + TJ) * 32] |d|^2 of the workgroup's atoms (0: beyond the dictionary)
   double* s_ay = s_aa + (TI + TJ) * 32;                    // [(TI + TJ) * 32] d.y
-  float2* s_it = (float2*)(s_ay + (TI + TJ) * 32);         // [2][(TI + TJ) * 32][KB] {z', |d'|} of the block's (atom, third atom) items (|d'| = 0: always pass)
-  float* s_uu = (float*)(s_it + 2 * (TI + TJ) * 32 * KB);  // [2][(TI + TJ) * 32][KB] u = d.d3/|d3| (FP32)
-  float* s_b3 = s_uu + 2 * (TI + TJ) * 32 * KB;            // [2][KB][4] per third atom: T - z3^2, z3 = y.d3/|d3|, -, -
+  float* s_b3 = (float*)(s_ay + (TI + TJ) * 32);           // [2][KB][4] per third atom: T - z3^2, z3 = y.d3/|d3|, -, -
   unsigned* s_q = (unsigned*)(s_b3 + 2 * KB * 4);          // [2][MFX_K3M_Q] passing triples: (i local << 9) | (j local << 2) | kk
   int* s_qn = (int*)(s_q + 2 * MFX_K3M_Q);                 // [2]
   double* s_T = (double*)(s_qn + 2);                       // [3] the threshold of block b in slot b mod 3
@@ -343,6 +341,19 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
       }
     }
   }
+  // {z', |d'| (0: the item passes with every partner at this block's threshold, or lies inside span(d3)), u} of the item
+  // (atom a of dictionary `side`, third atom k3), for the rare paths below: re-read from the item array (the block's
+  // threshold constant Tp comes from s_b3) instead of being kept in LDS for every item of every block - two LDS stores and
+  // ~10 vector instructions per built item, 37 KB of LDS
+  const int nblk_items = (N + KB - 1) / KB;
+  auto item_stat = [&](int side, int a, int k3, float Tp, float& zit, float& nit, float& uu) {
+    const K3Item it = k.items[((((size_t)b * 2 + side) * nblk_items + (k3 / KB)) * N + min(a, N - 1)) * KB + (k3 % KB)];
+    const bool has = it.n > 0.0f;
+    const bool always = !(Tp > 0.0f) || (it.z > 0.0f && it.z * it.z >= Tp * (1.0f - 3e-6f));
+    zit = has ? it.z : -1e30f;
+    nit = (has && !always) ? it.n : 0.0f;
+    uu = ((float)it.uh + (float)it.um) + (float)it.ul;
+  };
   // score a passing triple from the Gram; list it when it reaches the running threshold (solve_k3.hip's score_triple)
   double best = 0.0;
   // (the Gram entries with the third atom come from the block's LDS copies: three random reads of an 18 MB matrix per
@@ -364,8 +375,14 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
     // test with the partner unconstrained).  Ten FP64 operations instead of score3's hundred and fifty.
     const double c13 = a12 * a23 - a13 * a22, c23 = a12 * a13 - a11 * a23, c33 = a11 * a22 - a12 * a12;
     const double D3 = y1 * c13 + y2 * c23 + y3 * c33;
-    const float2* itp = s_it + (size_t)par * (TI + TJ) * 32 * KB;
-    const bool alw = !(itp[il * KB + kk].y > 0.0f) || !(itp[(TI * 32 + jl) * KB + kk].y > 0.0f);   // an "always pass" item
+    bool alw;   // an "always pass" item
+    {
+      const float Tpb = s_b3[(par * KB + kk) * 4];
+      float z1_, n1_, u1_, z2_, n2_, u2_;
+      item_stat(0, i, k3, Tpb, z1_, n1_, u1_);
+      item_stat(1, j, k3, Tpb, z2_, n2_, u2_);
+      alw = !(n1_ > 0.0f) || !(n2_ > 0.0f);
+    }
     if (!alw && D3 < -1e-10 * (fabs(y1 * c13) + fabs(y2 * c23) + fabs(y3 * c33)))
       s = score2(a11, a12, a22, y1, y2);
     else
@@ -467,12 +484,6 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
         const unsigned uw = valid ? cur[r].z : 0u;           // halves (uh, um) of u
         const unsigned lw = valid ? cur[r].w : 0u;           // halves (ul, margin slot); the margin is 0 unless nrm > 0
         if (al == 0) { float* b3 = s_b3 + (buf * KB + kk) * 4; b3[0] = Tp; b3[1] = z3f; }   // (item (atom 0, kk) of the i1 side; beyond the dictionary: 1e30)
-        s_it[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = float2{has ? z : -1e30f, valid ? ((has && !always) ? nrm : 0.0f) : 1.0f};
-        typedef _Float16 k3_h2 __attribute__((ext_vector_type(2)));
-        {
-          const k3_h2 u01 = __builtin_bit_cast(k3_h2, uw), u2m = __builtin_bit_cast(k3_h2, lw);
-          s_uu[((size_t)buf * (TI + TJ) * 32 + al) * KB + kk] = ((float)u01[0] + (float)u01[1]) + (float)u2m[0];
-        }
         _Float16 ph, pl, qh, ql;
         k3_split16(P, ph, pl);
         k3_split16(Qv, qh, ql);
@@ -537,19 +548,20 @@ __global__ __launch_bounds__(MFX_K3M_TI * 64) __attribute__((amdgpu_waves_per_eu
             // score itself in FP32 from the items' statistics (the matrix-pipe test carries a margin ~1e-6 |d1||d2|, i.e.
             // 1e-5 .. 1e-4 of the projected quantities: in a voxel with a flat optimum millions of triples sit inside it);
             // (ii) the third atom's weight in the unconstrained optimum (see the accumulator inputs above)
-            const size_t itb = (size_t)buf * (TI + TJ) * 32 * KB;
-            const float2 it2 = s_it[itb + (TI * 32 + t * 32 + lr) * KB + kk];
-            const float u2f = s_uu[itb + (TI * 32 + t * 32 + lr) * KB + kk];
             const float* b3 = s_b3 + (buf * KB + kk) * 4;
             const float Tpf = b3[0], z3f = b3[1];
+            float2 it2;
+            float u2f;
+            item_stat(1, j0 + t * 32 + lr, k0 + kk, Tpf, it2.x, it2.y, u2f);
 #pragma unroll 1
             for (int g = 0; g < 16; ++g) {
               bool hit = d[g] >= 0.0f;
               if (!__any(hit)) continue;
               if (hit && d[g] < 1e8f) {
                 const int ilr = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                const float2 it1 = s_it[itb + ilr * KB + kk];
-                const float u1f = s_uu[itb + ilr * KB + kk];
+                float2 it1;
+                float u1f;
+                item_stat(0, i0 + ilr, k0 + kk, Tpf, it1.x, it1.y, u1f);
                 if (it1.y > 0.0f && it2.y > 0.0f) {
                   // everything multiplied through by N12 = |d1'||d2'| (no division): c' = a / N12, a = a12 - u1 u2;
                   // E_i = e_i N12, DEN = (1 - c'^2) N12^2, NUM = num N12

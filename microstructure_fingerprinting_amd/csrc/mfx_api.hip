@@ -781,7 +781,7 @@ static int fit_k3_batched(const mfx_plan* p, const double* d_Y, const double* d_
   k.part = dpart.as<double>();
   k.w = dout.as<double>(); k.sub = (long*)(k.w + (size_t)BT * 8); k.minobj = (double*)(k.sub + (size_t)BT * 8); k.yrec = k.minobj + BT;
   const size_t lds = (size_t)2 * MFX_K3M_KB * ((MFX_K3M_TI + MFX_K3M_TJ) * 64 + 2 * MFX_K3M_PAD) * 16 + (size_t)(MFX_K3M_TI + MFX_K3M_TJ) * 32 * 16 +
-                     (size_t)2 * (MFX_K3M_TI + MFX_K3M_TJ) * 32 * MFX_K3M_KB * 12 + 2 * MFX_K3M_KB * 16 + 2 * MFX_K3M_Q * 4 + 16 + 32;
+                     2 * MFX_K3M_KB * 16 + 2 * MFX_K3M_Q * 4 + 16 + 32;
   HIPCHK(hipFuncSetAttribute((const void*)mfx_k3b_screen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   PackArgs pk{};
   pk.M = M; pk.K = 3; pk.has_csf = 0; pk.E = 0; pk.maxfasc = maxfasc; pk.csf_on = csf_on; pk.ear_on = ear_on; pk.num_params = num_params;
