@@ -898,7 +898,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
             const double* q = (sl == 0) ? d1s : ((sl == 1 || sl == 2) ? d2s : ((sl == 3) ? d1s : ((sl == 4) ? s_y : xx)));
             // (y1 += ym * d1, y2 += ym * d2: the products commute exactly)
             double acc = 0.0;
-            for (int m = 0; m < M; ++m) acc += p[m] * q[m];   // (NX == 1: the extra column has stride 1)
+#pragma unroll 8
+            for (int m = 0; m < M; ++m) acc += p[m] * q[m];   // (NX == 1: the extra column has stride 1; unrolled: the LDS reads of eight rows fly ahead of the sequential adds)
             s_sum[tid] = acc;
           }
           __builtin_amdgcn_wave_barrier();   // (a group sits inside one wave; its LDS operations execute in order)
@@ -910,6 +911,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void mfx_fit_k2x_kernel(F
               double u[3], r;
               auto explicit_res = [&](const double* ww) {
                 double rr = 0.0;
+#pragma unroll 8
                 for (int m = 0; m < M; ++m) {
                   const double tt = (ww[0] * d1s[m] + ww[1] * d2s[m] + ww[2] * xx[m] - s_y[m]);
                   rr += tt * tt;
