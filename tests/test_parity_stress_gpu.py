@@ -631,6 +631,35 @@ def test_three_fascicles_generic_class_vs_oracle():
             assert np.isclose(got[v, -2], mo / M, rtol=1e-6)
 
 
+def test_three_fascicles_in_a_mixed_roi_host_path():
+    """A ROI with one, two and three fascicles per voxel through ONE mfx_fit_batch call (class binning, voxel lists, the
+    batched three-fascicle path on a list of scattered voxels, 70 three-fascicle voxels = three batches): every row equals
+    the row of the same voxel fitted in a call of its own class."""
+    from microstructure_fingerprinting_amd import engine, synth
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    rng = np.random.default_rng(4242)
+    sch = synth.make_scheme(rng, 2, [1000, 2000, 3000], [30, 30, 30])
+    N = 96
+    dic = synth.make_dictionary(rng, sch, N)
+    ms = mfu.init_PGSE_multishell_interp(dic, sch, Z)
+    plan = ms.plan_for(sch)
+    V, M = 210, sch.shape[0]
+    Kv = np.tile([1, 2, 3], V // 3)
+    rng.shuffle(Kv)
+    peaks = np.concatenate([synth.unit_vectors(rng, V) for _ in range(3)], axis=1)
+    atoms = rng.integers(0, N, (V, 3))
+    nu = rng.dirichlet(np.ones(3), V) * (np.arange(3)[None, :] < Kv[:, None])
+    Y = rng.normal(0, 500.0 / 30.0, (V, M))
+    for k in range(3):
+        Y += 500.0 * nu[:, k:k + 1] * _rotate_cols(plan, peaks[:, 3 * k:3 * k + 3], atoms[:, k])
+    got = engine.fit_batch(plan, Y, Kv, None, None, peaks, 3, False, False)
+    for K in (1, 2, 3):
+        sel = np.flatnonzero(Kv == K)
+        alone = engine.fit_batch(plan, Y[sel], np.full(sel.size, K), None, None, peaks[sel], 3, False, False)
+        assert np.array_equal(got[sel], alone), K
+    assert np.all(got[Kv == 1][:, 2:4] == 0) and np.all(got[Kv == 3][:, 0] > 0)
+
+
 def test_fit_over_rotate_atom_plan_vs_oracle():
     """The voxel loop driven by rotate_atom tables (an explicit row plan: the dictionary is sampled on the subject's own
     protocol, mf_utils.py:1205-1437 - the reference's test_hcp_dict shape of use) on the HCP-MGH fixture (552 rows x 782
