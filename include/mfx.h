@@ -54,7 +54,7 @@ typedef struct mfx_plan mfx_plan;     /* device-resident per-protocol row plan  
 
 const char* mfx_last_error(void);
 int mfx_device_count(void);
-/* library/ABI version, bumped on any signature change or new entry point (3: mfx_fit_batch_volume, counters 8-10 of
+/* library/ABI version, bumped on any signature change or new entry point (3: mfx_fit_batch_volume, mfx_volume_rows, counters 8-10 of
  * mfx_debug_last_counter, mfx_debug_set_k3_cap, mfx_debug_set_force_generic, mfx_debug_set_k3_screen) */
 int mfx_abi_version(void);
 
@@ -131,6 +131,11 @@ int mfx_fit_batch_volume(const mfx_plan* p, const void* vol, int vol_dtype, doub
                          int64_t nvox, const int64_t* vox, const int32_t* K, const uint8_t* csf, const uint8_t* ear,
                          const double* peaks, int maxfasc, int csf_on, int ear_on, const double* sig_csf,
                          const double* sig_ear, int E, int64_t V, double* params_out);
+/* The same conversion + gather for any other per-voxel quantity that comes as a file-order volume of ncomp components
+ * (fascicle directions, tensors, colatitude / longitude: what MFModel.fit reads beside the data, mf.py:693-800, and
+ * indexes with `[mask > 0]` like the data): rows_out [V x ncomp] float64 on the HOST.  Runs on `device`. */
+int mfx_volume_rows(const void* vol, int vol_dtype, double scl_slope, double scl_inter, int64_t nvox, int ncomp,
+                    const int64_t* vox, int64_t V, double* rows_out, int device);
 /* mfx_fit_batch / mfx_fit_batch_rows / mfx_fit_batch_volume keep their pinned staging buffers and device buffers (signals, directions,
  * parameters) in the calling thread's state between calls and only ever grow them, so that a volume fitted slab by
  * slab (the reference's loop, mf.py:976-1032) pays no allocation per call; every entry point's scratch memory lives

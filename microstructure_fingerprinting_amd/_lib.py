@@ -20,7 +20,7 @@ EXPORTS = [
     "mfx_last_error", "mfx_device_count", "mfx_abi_version",
     "mfx_tables_create", "mfx_tables_destroy", "mfx_tables_num_atoms",
     "mfx_plan_create_multishell", "mfx_plan_create_explicit", "mfx_plan_destroy", "mfx_plan_status",
-    "mfx_rotate", "mfx_rotate_dev", "mfx_rotate_cols", "mfx_rotate_cols_dev", "mfx_fit_batch", "mfx_fit_batch_rows", "mfx_fit_batch_volume", "mfx_thread_release", "mfx_fit_batch_dev",
+    "mfx_rotate", "mfx_rotate_dev", "mfx_rotate_cols", "mfx_rotate_cols_dev", "mfx_fit_batch", "mfx_fit_batch_rows", "mfx_fit_batch_volume", "mfx_volume_rows", "mfx_thread_release", "mfx_fit_batch_dev",
     "mfx_solve_exhaustive", "mfx_monte_carlo_average", "mfx_monte_carlo_average_dev", "mfx_cleanup_2fascicles", "mfx_cleanup_2fascicles_dev", "mfx_last_kernel_ms", "mfx_set_profiling", "mfx_debug_set_stamps", "mfx_debug_last_fallback_count", "mfx_debug_last_guard_count", "mfx_debug_last_counter", "mfx_debug_set_k2_screen", "mfx_debug_set_k2_wide", "mfx_debug_set_k2x_screen", "mfx_debug_set_k2_maxc", "mfx_debug_set_k2x_maxc", "mfx_debug_set_k2s_cap", "mfx_debug_set_k2s_images", "mfx_debug_set_k3_cap", "mfx_debug_set_force_generic", "mfx_debug_set_k3_screen",
 ]
 
@@ -63,6 +63,7 @@ def lib():
     L.mfx_fit_batch_rows.argtypes = [vp, dp, lp, ip, bp, bp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int64, dp]
     L.mfx_fit_batch_volume.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_int64, lp, ip, bp, bp, dp, C.c_int, C.c_int,
                                        C.c_int, dp, dp, C.c_int, C.c_int64, dp]
+    L.mfx_volume_rows.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int, lp, C.c_int64, dp, C.c_int]
     L.mfx_fit_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp]
     L.mfx_solve_exhaustive.argtypes = [dp, C.c_int64, C.c_int, lp, C.c_int, dp, dp, lp, lp, dp, dp]
     L.mfx_monte_carlo_average.argtypes = [dp, C.c_int64, C.c_int, lp, dp, C.c_double, C.c_int64, C.c_int64, dp, C.c_int]

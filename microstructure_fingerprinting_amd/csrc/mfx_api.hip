@@ -1320,6 +1320,51 @@ extern "C" int mfx_fit_batch_volume(const mfx_plan* p, const void* vol, int vol_
   return fit_batch_host(p, src, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf, sig_ear, E, V, params_out);
 }
 
+// The same gather for any per-voxel quantity that arrives as a file-order volume (fascicle directions, tensors: what
+// MFModel.fit reads beside the data, mf.py:693-800): rows_out [V x ncomp] float64 on the host.
+extern "C" int mfx_volume_rows(const void* vol, int vol_dtype, double scl_slope, double scl_inter, int64_t nvox, int ncomp,
+                               const int64_t* vox, int64_t V, double* rows_out, int device) {
+  if (!vol || !vox || !rows_out || nvox <= 0 || ncomp < 1 || V < 0) return fail(MFX_ERR_ARG, "mfx_volume_rows: bad argument");
+  const size_t es = volume_elem_bytes(vol_dtype);
+  if (!es) return fail(MFX_ERR_ARG, "mfx_volume_rows: unsupported NIfTI data type %d", vol_dtype);
+  if (V == 0) return MFX_OK;
+  if (V > 0x7fffffff) return fail(MFX_ERR_ARG, "V too large");
+  for (int64_t v = 0; v < V; ++v)
+    if (vox[v] < 0 || vox[v] >= nvox) return fail(MFX_ERR_ARG, "mfx_volume_rows: voxel %lld: index %lld outside the volume", (long long)v, (long long)vox[v]);
+  if (int rc = require_device(device)) return rc;
+  const size_t vol_bytes = es * (size_t)nvox * (size_t)ncomp;
+  if (int rc = pipe_setup(device, std::min<size_t>(vol_bytes, (size_t)64 << 20))) return rc;
+  MfxThread& T = mfx_thread();
+  PoolPtr dvol, dvox;
+  if (int rc = pool_get(4, vol_bytes, &dvol.p)) return rc;
+  if (int rc = pool_get(5, sizeof(int64_t) * (size_t)V, &dvox.p)) return rc;
+  DevMem drows;
+  HIPCHK(drows.alloc(sizeof(double) * (size_t)V * ncomp));
+  HostSource src;
+  src.vol = vol; src.dtype = vol_dtype; src.slope = scl_slope; src.inter = scl_inter; src.nvox = nvox; src.vox = vox;
+  auto run = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(dvox.p, vox, sizeof(int64_t) * (size_t)V, hipMemcpyHostToDevice, T.s_comp));
+    const size_t slice = T.stage_bytes;
+    int64_t q = 0;
+    for (size_t o = 0; o < vol_bytes; o += slice, ++q) {
+      const size_t nb = std::min(slice, vol_bytes - o);
+      if (q >= 2) HIPCHK(hipEventSynchronize(T.ev_h2d[q & 1]));
+      std::memcpy(T.stage[q & 1], (const char*)vol + o, nb);
+      HIPCHK(hipMemcpyAsync((char*)dvol.p + o, T.stage[q & 1], nb, hipMemcpyHostToDevice, T.s_copy));
+      HIPCHK(hipEventRecord(T.ev_h2d[q & 1], T.s_copy));
+    }
+    HIPCHK(hipStreamWaitEvent(T.s_comp, T.ev_h2d[(q + 1) & 1], 0));
+    if (int rc = volume_gather_launch(src, dvol.p, dvox.as<long long>(), (int)V, ncomp, drows.as<double>(), T.s_comp)) return rc;
+    HIPCHK(hipMemcpyAsync(rows_out, drows.p, sizeof(double) * (size_t)V * ncomp, hipMemcpyDeviceToHost, T.s_comp));
+    return MFX_OK;
+  };
+  int rc = run();
+  const hipError_t e1 = hipStreamSynchronize(T.s_copy), e2 = hipStreamSynchronize(T.s_comp);
+  if (rc == MFX_OK && (e1 != hipSuccess || e2 != hipSuccess))
+    rc = fail(MFX_ERR_HIP, "mfx_volume_rows failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  return rc;
+}
+
 extern "C" int mfx_fit_batch(const mfx_plan* p, const double* Y, const int32_t* K, const uint8_t* csf,
                              const uint8_t* ear, const double* peaks, int maxfasc, int csf_on, int ear_on,
                              const double* sig_csf, const double* sig_ear, int E, int64_t V, double* params_out) {

@@ -108,6 +108,22 @@ class FileOrderVolume(object):
         return np.ravel_multi_index(np.unravel_index(c_flat_index, grid), grid, order='F').astype(np.int64)
 
 
+def volume_rows(vol, vox, device=0):
+    """mfx_volume_rows: ``vol.get_fdata().reshape(-1, n, order='F')[vox]`` (float64 [V x n]) with the conversion, scaling
+    and gather on the device - for the per-voxel quantities MFModel.fit indexes with the mask beside the data."""
+    a = vol.array
+    n = a.shape[-1]
+    nvox = int(np.prod(a.shape[:-1]))
+    vox = np.ascontiguousarray(vox, dtype=np.int64)
+    V = vox.shape[0]
+    if V and (vox.min() < 0 or vox.max() >= nvox):
+        raise ValueError("voxel indices out of range")
+    out = np.zeros((V, n))
+    L.check(L.lib().mfx_volume_rows(a.ctypes.data, FileOrderVolume.NIFTI_CODES[a.dtype.str[1:]], vol.slope, vol.inter, nvox, n,
+                                    L.lptr(vox), V, L.dptr(out), int(device)))
+    return out
+
+
 def fit_batch_volume(plan, vol, vox, K, csf, ear, peaks, maxfasc, csf_on, ear_on, sig_csf=None, sig_ear=None, E=0):
     """mfx_fit_batch_volume: like ``fit_batch(plan, vol.get_fdata().reshape(-1, M, order='F')[vox], ...)`` with the
     volume uploaded in its own layout and type and the conversion, scaling and ROI gather (mf.py:623-657) on the device."""

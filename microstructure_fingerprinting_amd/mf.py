@@ -161,6 +161,12 @@ class MFModel():
         roi = mask_arr > 0
         roi_index = np.flatnonzero(roi.reshape(-1))     # ROI order == np.where(mask > 0) (C order)
         ROI_size = int(roi_index.shape[0])
+        _fidx = []
+
+        def file_order_roi():   # the ROI voxels' positions inside one 3-D image of a file-order volume (computed once)
+            if not _fidx:
+                _fidx.append(np.ravel_multi_index(np.unravel_index(roi_index, img_shape), img_shape, order='F').astype(np.int64))
+            return _fidx[0]
         if ROI_size == 0:
             raise ValueError("No voxel detected in mask. Please provide a non-empty mask.")
         if data_arr.shape[:-1] != img_shape:
@@ -196,8 +202,15 @@ class MFModel():
             if pk.shape[-1] > maxfasc * 3 and VRB >= 1:
                 print("Ignoring last %d value(s) along last dimension of peaks, as max number of axon populations "
                       "in mask is %d." % (pk.shape[-1] - maxfasc * 3, maxfasc))
-            peaks_roi = np.ascontiguousarray(np.asarray(pk).reshape(-1, pk.shape[-1])[roi_index, :3 * maxfasc],
-                                             dtype=np.float64)
+            pk = np.asarray(pk)
+            if engine.FileOrderVolume.accepts(pk) and ROI_size >= 4096:
+                # a file-order (Fortran) volume: reshaping it to C-order rows would first copy the whole volume on one
+                # host core (0.2-0.6 s at 1e6 ROI voxels) - the device gathers it like the data
+                fov = engine.FileOrderVolume(pk)
+                peaks_roi = np.ascontiguousarray(engine.volume_rows(fov, file_order_roi(),
+                                                                    device=self.ms_interpolator.device)[:, :3 * maxfasc])
+            else:
+                peaks_roi = np.ascontiguousarray(pk.reshape(-1, pk.shape[-1])[roi_index, :3 * maxfasc], dtype=np.float64)
         elif colat_longit is not None or tensors is not None:
             arg = colat_longit if colat_longit is not None else tensors
             dims = ((2,),) if colat_longit is not None else ((6,), (1, 6))
@@ -291,7 +304,7 @@ class MFModel():
         # numbers: the library gathers the rows while it stages the upload (the reference's data[mask > 0], ref:644)
         if vol is not None:
             Y = vol
-            rows = vol.file_order_index(roi_index)
+            rows = file_order_roi()
         elif isinstance(data_arr, np.ndarray) and data_arr.dtype == np.float64 and data_arr.flags.c_contiguous:
             Y = data_arr.reshape(-1, num_seq)
             rows = roi_index.astype(np.int64, copy=False)
