@@ -116,6 +116,7 @@ def test_volume_scalar_types_and_scaling():
         Yf = vol.get_fdata().reshape(-1, M, order="F")[vox]
         ref = engine.fit_batch(plan, Yf, Kv, None, None, pk, 1, False, False)
         assert np.array_equal(got, ref), dt
+        assert np.array_equal(engine.volume_rows(vol, vox), Yf), dt      # mfx_volume_rows: the gather alone, rows back on the host
     with pytest.raises(ValueError):
         engine.fit_batch_volume(plan, vol, np.array([nvox]), np.array([1]), None, None, Z[None], 1, False, False)
 
