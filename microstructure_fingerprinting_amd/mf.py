@@ -167,6 +167,14 @@ class MFModel():
             if not _fidx:
                 _fidx.append(np.ravel_multi_index(np.unravel_index(roi_index, img_shape), img_shape, order='F').astype(np.int64))
             return _fidx[0]
+
+        def roi_rows(arr):      # arr[mask > 0] of a (grid x n) volume as float64 rows
+            if engine.FileOrderVolume.accepts(arr) and arr.shape[:-1] == img_shape and ROI_size >= 4096:
+                # a file-order (Fortran) volume: indexing it with the C-ordered mask, or reshaping it to C-order rows,
+                # first copies the whole volume on one host core (0.2-0.6 s at 1e6 ROI voxels) - the device gathers it
+                # like the data (mfx_volume_rows)
+                return engine.volume_rows(engine.FileOrderVolume(arr), file_order_roi(), device=self.ms_interpolator.device)
+            return np.asarray(arr.reshape(-1, arr.shape[-1])[roi_index], dtype=np.float64)
         if ROI_size == 0:
             raise ValueError("No voxel detected in mask. Please provide a non-empty mask.")
         if data_arr.shape[:-1] != img_shape:
@@ -202,15 +210,7 @@ class MFModel():
             if pk.shape[-1] > maxfasc * 3 and VRB >= 1:
                 print("Ignoring last %d value(s) along last dimension of peaks, as max number of axon populations "
                       "in mask is %d." % (pk.shape[-1] - maxfasc * 3, maxfasc))
-            pk = np.asarray(pk)
-            if engine.FileOrderVolume.accepts(pk) and ROI_size >= 4096:
-                # a file-order (Fortran) volume: reshaping it to C-order rows would first copy the whole volume on one
-                # host core (0.2-0.6 s at 1e6 ROI voxels) - the device gathers it like the data
-                fov = engine.FileOrderVolume(pk)
-                peaks_roi = np.ascontiguousarray(engine.volume_rows(fov, file_order_roi(),
-                                                                    device=self.ms_interpolator.device)[:, :3 * maxfasc])
-            else:
-                peaks_roi = np.ascontiguousarray(pk.reshape(-1, pk.shape[-1])[roi_index, :3 * maxfasc], dtype=np.float64)
+            peaks_roi = np.ascontiguousarray(roi_rows(np.asarray(pk))[:, :3 * maxfasc], dtype=np.float64)
         elif colat_longit is not None or tensors is not None:
             arg = colat_longit if colat_longit is not None else tensors
             dims = ((2,),) if colat_longit is not None else ((6,), (1, 6))
@@ -229,7 +229,8 @@ class MFModel():
                                      "have shape %s, got (%s) instead."
                                      % (i + 1, len(arg), want, " ".join("%d" % x for x in a_i.shape)))
                 if colat_longit is not None:
-                    th, ph = a_i[roi, 0], a_i[roi, 1]
+                    ang = roi_rows(a_i)
+                    th, ph = ang[:, 0], ang[:, 1]
                     peaks_roi[:, 3 * i + 0] = np.sin(th) * np.cos(ph)
                     peaks_roi[:, 3 * i + 1] = np.sin(th) * np.sin(ph)
                     peaks_roi[:, 3 * i + 2] = np.cos(th)
@@ -237,7 +238,7 @@ class MFModel():
                     if a_i.shape[mask_arr.ndim] == 1:
                         a_i = a_i[(slice(None),) * mask_arr.ndim + (0, slice(None))]
                     # NIfTI 'column' order of the upper triangle; principal eigenvector, 0 for zero tensors
-                    peaks_roi[:, 3 * i:3 * i + 3] = mfu.DT_vec_to_peaks(a_i[roi, :], 'column')
+                    peaks_roi[:, 3 * i:3 * i + 3] = mfu.DT_vec_to_peaks(roi_rows(a_i), 'column')
             peaks_roi = np.ascontiguousarray(peaks_roi[:, :3 * maxfasc])
             if peaks_roi.shape[1] < 3 * maxfasc:
                 peaks_roi = np.concatenate([peaks_roi, np.zeros((ROI_size, 3 * maxfasc - peaks_roi.shape[1]))], axis=1)

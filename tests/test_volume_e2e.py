@@ -48,6 +48,19 @@ def test_volume_files_to_maps(tmp_path):
     # (2) nibabel-style Fortran-ordered float64 array (get_fdata()) takes the volume path too
     fit_f = model.fit(np.asfortranarray(data64), ph["mask"], ph["numfasc"], **kwa)
     assert np.array_equal(fit_f.params_in_mask, fit.params_in_mask)
+    # (2b) directions as colatitude / longitude volumes and as tensor volumes in file order: the device gathers them too
+    # (mfx_volume_rows); the same rows as from C-ordered arrays
+    pkv = ph["peaks"]
+    cl = [np.stack([np.arccos(np.clip(pkv[..., 3 * k + 2], -1, 1)), np.arctan2(pkv[..., 3 * k + 1], pkv[..., 3 * k])], axis=-1) for k in range(2)]
+    from microstructure_fingerprinting_amd import mf_utils as mfu
+    dt = mfu.peaks_to_DT_vec(pkv.reshape(pkv.shape[:-1] + (2, 3)).copy(), 'column')          # one (grid x 6) array per fascicle
+    dirs_only = np.any(pkv[..., :3], axis=-1) & np.any(pkv[..., 3:], axis=-1) & (ph["mask"] > 0)   # both directions present
+    kw2 = dict(pgse_scheme=sch, csf_mask=ph["csf_mask"], ear_mask=ph["ear_mask"], verbose=0)
+    for key, vols in (("colat_longit", cl), ("tensors", dt)):
+        fc = model.fit(data64, dirs_only.astype(float), ph["numfasc"], **{key: [np.ascontiguousarray(v) for v in vols]}, **kw2)
+        ff = model.fit(data64, dirs_only.astype(float), ph["numfasc"], **{key: [np.asfortranarray(v) for v in vols]}, **kw2)
+        assert np.array_equal(fc.params_in_mask, ff.params_in_mask), key
+        assert fc.params_in_mask.shape[0] >= 4096
     # (3) parallel=True over two shards (the one GPU named twice: _fit_sharded with one host thread per shard)
     model.SHARD_DEVICES = [0, 0]
     try:
