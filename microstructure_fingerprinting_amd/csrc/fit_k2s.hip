@@ -54,6 +54,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef MFX_S_DC
 #define MFX_S_DC 1.5e-5
 #endif
+// The matrix-pipe term grows with the number of dependent instructions, 3 per k-step: longer protocols (KS = 16: up to 256
+// measurements here, KS = 24 / 35: the wide kernel) get the margin the same statement gives for them, with the same 5 % of head
+// room: 1.05 (2.38e-6 + 3 KS x 3.046e-7) = 1.79e-5, 2.55e-5, 3.61e-5.  (The audit of the wide kernel at 302 / 551 measurements:
+// largest |c~ - c| 9.9e-7 / 1.19e-6.)
+template <int KS>
+__host__ __device__ constexpr double mfx_s_dc() { return KS <= 13 ? (double)MFX_S_DC : 1.05 * (2.38e-6 + 3.0 * KS * 3.046e-7); }
 #define MFX_S_DENMIN 1e-3   // below this 1 - c~^2 the pair goes through the interval bound
 #define MFX_S_BOUND 0x40000000   // ring entry flag (in .j): .score is an upper bound (interval bound, single atom), not S(c~)
 #define MFX_S_GUARD 0.25    // run-time guard: an exactly evaluated pair whose screening score was off by more than this
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #ifdef MFX_STAMPS_RND
     int dbg_flagged = 0, dbg_groups = 0;   // accumulator tiles / register groups of this wave that reached the FP64 criteria
 #endif
-    const float DCF = XC ? (float)(((double)MFX_S_DC + 2e-6) * ramp) * (1.0f + 2e-7f)
-                         : (float)MFX_S_DC + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
+    const float DCF = XC ? (float)((mfx_s_dc<KS>() + 2e-6) * ramp) * (1.0f + 2e-7f)
+                         : (float)mfx_s_dc<KS>() + 2e-6f;   // + the FP32 evaluation error of t (< 1e-6 in cosine units)
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
       Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);

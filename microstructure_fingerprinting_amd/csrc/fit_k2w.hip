@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   int bn1 = 0;
   constexpr int TPR = NW * TL;   // row tiles per round
   const int nrounds = (ntiles + TPR - 1) / TPR;
+  // the voxel's audited pair: the key k2s_finish evaluates (its rule for the shared last tile: workgroup waves, not TPR)
+  const int aud_key = (!XC && a.audit) ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
   // generation items of a chunk image: (pair of adjacent atoms) x (the 8 rows of one MFMA fragment): 16 x 2 KS of them,
   // 8 KS per wave, a lane takes items l, l + 64, ... of its wave's share
   constexpr int IPW = 8 * KS;              // items per wave
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
     double thr_rows[TL];
 #pragma unroll
     for (int t = 0; t < TL; ++t) thr_rows[t] = -1.0;
-    const float DCF = XC ? (float)(((double)MFX_S_DC + 2e-6) * ramp) * (1.0f + 2e-7f) : (float)MFX_S_DC + 2e-6f;
+    const float DCF = XC ? (float)((mfx_s_dc<KS>() + 2e-6) * ramp) * (1.0f + 2e-7f) : (float)mfx_s_dc<KS>() + 2e-6f;
     auto pq_of = [&](float z, float rth, float& P, float& Q) {
       P = fminf(1.0f, fmaxf(z, 0.0f) * rth);
       Q = __builtin_amdgcn_sqrtf(fmaxf(0.0f, fmaf(-P, P, 1.0f) - 1.2e-7f)) * (1.0f - 3e-7f);
@@ -464,6 +466,23 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         __builtin_amdgcn_sched_barrier(0);
       });
     };
+    // the voxel's audited pair (k2s_shared.h, as in fit_k2s.hip): when its tile's accumulators are complete, the raw value of
+    // its register and lane is parked in LDS for the exact stage to compare with the FP64 cosine
+    auto audit_park = [&](auto pc, int ct) {
+      constexpr int P = decltype(pc)::value;
+      if (aud_key < 0) return;
+      mfx_static_for<0, TL>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (rtv[t] && ((rts[t] << 8) | ct) == aud_key) {
+          const unsigned h = k2s_audit_hash(vox);
+          const int ga = (h >> 16) & 15;
+          float v = accs[P][t][0];
+#pragma unroll
+          for (int g = 1; g < 16; ++g) v = (ga == g) ? accs[P][t][g] : v;
+          if (lane == (int)((h >> 20) & 63)) ((float*)(s_red + 30))[0] = v;
+        }
+      });
+    };
     // what is left of chunk c-1's screen after the slices: the FP64 criteria of the flagged groups (rare)
     auto screen_finish = [&](auto pc, int ct) {
       constexpr int P = decltype(pc)::value;
@@ -499,6 +518,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         if (do_scr) screen_begin(c - 1);
         MFX_WSTAMP(1);
         mfma_chunk(pc, c & 1, do_scr, do_gen, (c + 1) & 1);
+        audit_park(pc, c);
         MFX_WSTAMP(2);
         if (do_scr) screen_finish(pc, c - 1);
         MFX_WSTAMP(3);
@@ -526,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
         const bool do_scr = c >= 1;
         if (do_scr) screen_begin(c - 1);
         mfma_chunk(pc, 0, do_scr, false, 0);
+        audit_park(pc, c);
         if (do_scr) screen_finish(pc, c - 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       };

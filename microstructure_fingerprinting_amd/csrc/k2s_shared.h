@@ -355,7 +355,7 @@ __device__ __forceinline__ K2sVoxel k2s_prologue(const FitK2Args& a, const K2sLd
     ramp_v = sqrt(fmax(1.0, __longlong_as_double((long long)rw[0]))) * sqrt(fmax(1.0, __longlong_as_double((long long)rw[1])));
   }
   const double ramp = mfx_readlane_f64(ramp_v, 0);
-  const double dc_eff = XC ? MFX_S_DC * ramp : MFX_S_DC;                 // bound on |c~ - c| in the units of the test
+  const double dc_eff = XC ? mfx_s_dc<KS>() * ramp : mfx_s_dc<KS>();     // bound on |c~ - c| in the units of the test
   // XC: the projected statistics cancel - z' |d'| = d.y - u yx - so the FP32 rounding of table, signal and column
   // (<= 3.6e-7 |d||y| in that difference) is no longer negligible when most of the signal is x: + 2e-6 ramp |y||y'| in a
   // score, + 2e-6 ramp |y| in e.  And never below the exact kernel's own tie tolerance, 1e-9 |y|^2: what it would
@@ -684,7 +684,7 @@ __device__ __forceinline__ void k2s_finish(const FitK2Args& a, const K2sLds<KS, 
           if (lane == 0) {
             atomicAdd(a.audit + 2, 1);
             atomicMax(a.audit + 1, (int)fmin(err * 1e11, 2.0e9));
-            if (err > 0.25 * MFX_S_DC) atomicAdd(a.audit, 1);
+            if (err > 0.25 * mfx_s_dc<KS>()) atomicAdd(a.audit, 1);
           }
         }
       }
