@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
 #ifdef MFX_EXP_NOAUDIT   // timing experiment
   const int aud_key = -1;
 #else
-  const int aud_key = (!XC && a.audit) ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
+  const int aud_key = a.audit ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
 #endif
   for (int round = 0; round < nrounds; ++round) {
     // A last round with ONE row tile left (N = 782: 25 = 3*8 + 1) is shared by all waves: each keeps the same
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void mfx_fit_k2s_kernel(FitK2Args a) {
       ++dbg_calls;
 #endif
       MFX_SCAN_T(0);
-      if constexpr (!XC) {
+      {
         if (((rt << 8) | ct) == aud_key) {   // once per voxel, one wave: park the raw accumulator value of the audited pair (k2s_shared.h)
           const unsigned h = k2s_audit_hash(vox);
           const int ga = (h >> 16) & 15;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 1) void mfx_fit_k2w_kernel(FitK2Args a) {
   constexpr int TPR = NW * TL;   // row tiles per round
   const int nrounds = (ntiles + TPR - 1) / TPR;
   // the voxel's audited pair: the key k2s_finish evaluates (its rule for the shared last tile: workgroup waves, not TPR)
-  const int aud_key = (!XC && a.audit) ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
+  const int aud_key = a.audit ? k2s_audit_key(k2s_audit_hash(vox), (ntiles % NW == 1 && ntiles > 1) ? ntiles - 1 : ntiles, ntiles) : -1;
   // generation items of a chunk image: (pair of adjacent atoms) x (the 8 rows of one MFMA fragment): 16 x 2 KS of them,
   // 8 KS per wave, a lane takes items l, l + 64, ... of its wave's share
   constexpr int IPW = 8 * KS;              // items per wave

@@ -509,6 +509,38 @@ __device__ __forceinline__ void k2s_finish(const FitK2Args& a, const K2sLds<KS, 
     return;
   }
   if constexpr (XC) {
+    // population audit of the [N, N, 1] form (see k2s_audit_hash): its accumulator holds d1.d2 - u1 u2 with the FP32 projections
+    // u = d.x/|x| of the statistics pass in the spare row; wave 0 compares the parked value of the voxel's audited pair, in units
+    // of |d1||d2|, with the FP64 sum over the FP64 table minus the product of the same two projections
+    if (a.audit && wave == 0) {
+      const float accv = ((const float*)(s_red + 30))[0];
+      if (accv == accv) {
+        const unsigned h = k2s_audit_hash(vox);
+        const int ntl = NP >> 5;
+        const int key = k2s_audit_key(h, (ntl % NW == 1 && ntl > 1) ? ntl - 1 : ntl, ntl);
+        const int ga = (h >> 16) & 15, la = (h >> 20) & 63;
+        const int i = (key >> 8) * 32 + (ga & 3) + 8 * (ga >> 2) + 4 * (la >> 5), j = (key & 0xff) * 32 + (la & 31);
+        if (i < N && j < N) {   // (wave-uniform)
+          double a11 = 0.0, a22 = 0.0, a12 = 0.0;
+          for (int m = lane; m < M; m += 64) {
+            const double d1 = elem(0, m, i), d2 = elem(1, m, j);
+            a11 += d1 * d1; a22 += d2 * d2; a12 += d1 * d2;
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { a11 += __shfl_xor(a11, o); a22 += __shfl_xor(a22, o); a12 += __shfl_xor(a12, o); }
+          const double u1 = (double)s_uf[i], u2 = (double)s_uf[NP + j], p1 = (double)s_cs[i], p2 = (double)s_cs[NP + j];
+          const double n12 = sqrt((p1 * p1 + u1 * u1) * (p2 * p2 + u2 * u2));     // |d1||d2| in the accumulator's units
+          if (n12 > 0.0 && a11 > 0.0 && a22 > 0.0) {
+            const double err = fabs((double)accv / n12 - (a12 / (sqrt(a11) * sqrt(a22)) - (u1 * u2) / n12));
+            if (lane == 0) {
+              atomicAdd(a.audit + 2, 1);
+              atomicMax(a.audit + 1, (int)fmin(err * 1e11, 2.0e9));
+              if (err > 0.25 * mfx_s_dc<KS>()) atomicAdd(a.audit, 1);
+            }
+          }
+        }
+      }
+    }
     // the ring entries that reach the final threshold -> this voxel's short list (scores in projected units, + yx^2 in all)
     int* s_evl = (KS >= 8) ? (int*)((char*)smem + 2048) : s_evl4;
     if (tid == 0) s_cnt[2] = 0;

@@ -86,7 +86,9 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   const int chunk = 2048, big = 32768, cap = MFX_XLCAP;
   const int nc = std::min(chunk, nvox), nb = std::min(big, nvox);
   const size_t slab = (size_t)2 * a.T.ldn * (MFX_XS + 2 * (ntup + 1));
-  StreamMem ws(st), cnt(st), fbm(st), xlc(st), xln(st), xlm(st);
+  StreamMem ws(st), cnt(st), fbm(st), xlc(st), xln(st), xlm(st), aud(st);
+  HIPCHK(aud.alloc(4 * sizeof(int)));      // population audit of the screening kernel: beyond DC/4, largest error (1e-11), pairs
+  HIPCHK(hipMemsetAsync(aud.p, 0, 4 * sizeof(int), st));
   HIPCHK(ws.alloc(sizeof(double) * slab * nc));
   HIPCHK(cnt.alloc(4 * sizeof(int)));
   HIPCHK(fbm.alloc(sizeof(int) * ((size_t)nvox + 4)));   // [0] voxels handed back, [1] of them by the bound check, [4..] their list
@@ -107,6 +109,7 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   s.params = a.params; s.num_params = a.num_params; s.maxfasc = a.maxfasc; s.csf_on = a.csf_on; s.ear_on = a.ear_on;
   s.stamps = nullptr; s.fb_count = fb; s.fb_list = fb + 4; s.maxc = 0; s.scap = T.k2s_cap ? T.k2s_cap : MFX_S_CAP;
   s.xc = a.X.x; s.xl_cand = xlc.as<Cand>(); s.xl_cnt = xln.as<int>(); s.xl_mrg = xlm.as<double>(); s.xl_cap = cap;
+  s.audit = aud.as<int>();
   if (int rc = mfx_prof_begin(st)) return rc;
   for (int base = 0; base < nvox; base += big) {
     const int n = std::min(big, nvox - base);
@@ -126,6 +129,7 @@ static int launch_k2sx_pipeline(FitK2XArgs a, int nvox, hipStream_t st) {
   HIPCHK(hipGetLastError());
   if (int rc = mfx_prof_end(st)) return rc;
   if (int rc = mfx_fb_accumulate(fb, 2, st, 4)) return rc;   // counters [4], [5]: voxels handed to the plain kernel, of them by the bound check
+  if (int rc = mfx_fb_accumulate_audit(aud.as<int>(), st)) return rc;
   return mfx_fb_accumulate(cnt.as<int>(), 4, st);
 }
 

@@ -997,6 +997,9 @@ def test_k2_csf_screening_pipeline_vs_plain_kernel_and_oracle():
     args = (plan, Y, np.full(V, 2), one, zero, peaks, 2, True, False, sig_csf, None, 0)
     got = engine.fit_batch(*args)
     cn = [lib.mfx_debug_last_counter(q) for q in range(6)]
+    aud = [lib.mfx_debug_last_counter(q) for q in (8, 9, 10)]
+    # population audit of the [N, N, 1] screening kernel: one pseudo-random pair per screened voxel, d1.d2 - u1 u2 against FP64
+    assert aud[2] > 0.5 * V and aud[0] == 0 and aud[1] * 1e-11 < 0.25 * 1.5e-5, aud
     lib.mfx_debug_set_k2x_screen(0)
     try:
         plain = engine.fit_batch(*args)

@@ -30,7 +30,7 @@ d_out = engine.fit_batch_dev(plan, d_Y, d_peaks, 2, csf_on=bool(CSF), ear_on=boo
                              d_sig_ear=d_ear if EAR else None, E=E if EAR else 0)
 torch.cuda.synchronize()
 lib = L.lib()
-print("GPU done; counters", [lib.mfx_debug_last_counter(q) for q in range(6)], flush=True)
+print("GPU done; counters", [lib.mfx_debug_last_counter(q) for q in range(6)], "audit (beyond DC/4, max err 1e-11, pairs)", [lib.mfx_debug_last_counter(q) for q in (8, 9, 10)], flush=True)
 got = d_out.cpu().numpy()
 Y = d_Y.cpu().numpy()
 T = {"S": ms.S, "N": ms.num_subs, "G_un": ms.Gms_un, "off": ms.off, "x": ms.x_flat, "Y": ms.Y_flat}
